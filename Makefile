@@ -1,0 +1,33 @@
+# Builds the product library (HIP kernels + C ABI + host scene layer) for gfx950 and the
+# CPU oracle (test infrastructure only; the product never links it).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CXXSTD = -std=c++17
+HIPFLAGS = --offload-arch=$(ARCH) -O3 $(CXXSTD) -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function
+HOSTFLAGS = -O2 $(CXXSTD) -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off
+
+LIB = raytracing_amd/librt_amd.so
+HOST_SRC = raytracing_amd/host/scene.cpp raytracing_amd/host/flatten.cpp raytracing_amd/host/config.cpp \
+           raytracing_amd/host/image_io.cpp raytracing_amd/host/host_capi.cpp
+HOST_OBJ = $(HOST_SRC:.cpp=.o)
+DEV_OBJ = raytracing_amd/csrc/rt_device.o
+
+all: $(LIB) oracle
+
+$(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_math.h include/rt_amd.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+raytracing_amd/host/%.o: raytracing_amd/host/%.cpp raytracing_amd/host/raytracing.hpp include/rt_amd.h
+	g++ $(HOSTFLAGS) -c $< -o $@
+
+$(LIB): $(DEV_OBJ) $(HOST_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(DEV_OBJ) $(HOST_OBJ) -lz
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB) $(DEV_OBJ) $(HOST_OBJ)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

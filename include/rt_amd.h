@@ -1,0 +1,298 @@
+/*
+ * rt_amd.h -- C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * The reference (piemot/raytracing) has no FFI; the seam this library replaces is
+ *     pub fn render(&mut self, world: &impl Hittable, lights: Rc<dyn Hittable>)   src/camera.rs:368
+ * i.e. the pixel/stratum loop of camera.rs:386-401 together with everything it calls
+ * (get_ray :409, ray_color :432, Hittable::hit, Material::*, PDF::*).  A reference-side
+ * binding flattens its scene graph into the arrays below, calls rt_render() once per
+ * stratum range, and hands the returned film to its own ImageWriter (export.rs:5-8).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * negative code on failure (nothing unwinds across the ABI); rt_last_error() gives the text.
+ * One handle per GPU.  Calls on one handle are not re-entrant; different handles may be
+ * driven from different host threads.  All `const T*` arguments are caller-owned HOST
+ * memory unless the name says device.
+ *
+ * Part 1 (rt_*)  : device backend -- scene upload, wavefront render, film, parity hook.
+ * Part 2 (rth_*) : host scene layer -- C view of the C++ mirror of the reference's scene /
+ *                  camera / config API (raytracing_amd/host/raytracing.hpp), which builds
+ *                  the BVH on the host and flattens to rt_scene_desc.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ flat scene layout */
+
+/* 32-bit reference = kind << 29 | index */
+#define RT_REF_KIND_SHIFT 29u
+#define RT_REF_INDEX_MASK 0x1FFFFFFFu
+#define RT_KIND_NODE 0u   /* index into nodes[] */
+#define RT_KIND_QUAD 1u   /* index into quads[] (parallelogram / triangle / disc) */
+#define RT_KIND_SPHERE 2u /* index into spheres[] */
+#define RT_KIND_MEDIUM 3u /* index into media[] */
+#define RT_REF_NONE 0xFFFFFFFFu
+
+/* BVH node, 64 B.  Interior: boxes of both children + child refs (any kind).
+ * Leaf list (right == RT_NODE_LEAF): refs[left .. left+count) are scanned in order, which is
+ * the order HittableVec::hit visits them (hittable.rs:252-264). */
+#define RT_NODE_LEAF 0xFFFFFFFFu
+typedef struct {
+    float lmin[3];
+    uint32_t left;
+    float lmax[3];
+    uint32_t right;
+    float rmin[3];
+    uint32_t count;
+    float rmax[3];
+    uint32_t pad;
+} rt_node;
+
+/* Quad-family primitive, 96 B (hittable.rs:281-677 with Translate/RotateY baked in).
+ * avec = v x w and bvec = w x u so that alpha = (p-Q).avec, beta = (p-Q).bvec
+ * (same value as w.((p-Q) x v) and w.(u x (p-Q)) at hittable.rs:357-358). */
+#define RT_SHAPE_PARALLELOGRAM 0u
+#define RT_SHAPE_TRIANGLE 1u
+#define RT_SHAPE_DISC 2u
+typedef struct {
+    float q[3], d;      /* corner, plane constant D = normal . Q */
+    float n[3], area;   /* unit normal, |u x v| */
+    float avec[3];
+    uint32_t shape;
+    float bvec[3];
+    uint32_t mat;
+    float u[3];
+    uint32_t prim_id;
+    float v[3];
+    uint32_t pad;
+} rt_quad;
+
+/* Sphere, 48 B (hittable.rs:117-209): centre(time) = c0 + time * cv */
+typedef struct {
+    float c0[3], radius;
+    float cv[3];
+    uint32_t mat;
+    uint32_t prim_id, moving, pad0, pad1;
+} rt_sphere;
+
+/* ConstantMedium (hittable.rs:820-891): boundary = refs[first .. first+count), a convex list */
+typedef struct {
+    uint32_t first, count;
+    float neg_inv_density;
+    uint32_t mat;
+    uint32_t prim_id, pad0, pad1, pad2;
+} rt_medium;
+
+#define RT_MAT_LAMBERTIAN 0u
+#define RT_MAT_LIGHT 1u
+#define RT_MAT_METAL 2u
+#define RT_MAT_DIELECTRIC 3u
+#define RT_MAT_ISOTROPIC 4u
+typedef struct {
+    uint32_t type, tex; /* tex unused for metal / dielectric */
+    float albedo[3];
+    float param;        /* fuzz or refraction index */
+    uint32_t needs_uv, pad;
+} rt_material;
+
+#define RT_TEX_SOLID 0u
+#define RT_TEX_CHECKER 1u
+#define RT_TEX_IMAGE 2u
+#define RT_TEX_NOISE 3u
+typedef struct {
+    uint32_t type;
+    float color[3];    /* solid */
+    float scale;       /* checker: 1/scale as the reference multiplies (texture.rs:61); noise: scale */
+    uint32_t a, b;     /* checker: even / odd texture ids; image: width / height */
+    uint32_t offset;   /* image: byte offset into texels; noise: index of its table */
+} rt_texture;
+
+#define RT_LIGHTS_NONE 0u
+#define RT_LIGHTS_SINGLE 1u /* `lights` is one primitive: no selection draw */
+#define RT_LIGHTS_LIST 2u   /* `lights` is a list: uniform pick, averaged pdf */
+typedef struct {
+    uint32_t n_nodes, n_refs, n_quads, n_spheres, n_media, n_materials, n_textures, n_lights;
+    uint32_t n_texel_bytes, n_noise; /* noise tables: n_noise * (256*4 floats + 3*256 ints) */
+    uint32_t root;                   /* ref of the world */
+    uint32_t lights_kind;
+    uint32_t n_prims;                /* number of user-visible primitive ids */
+    uint32_t max_stack;              /* traversal stack depth this scene needs */
+    const rt_node *nodes;
+    const uint32_t *refs;
+    const rt_quad *quads;
+    const rt_sphere *spheres;
+    const rt_medium *media;
+    const rt_material *materials;
+    const rt_texture *textures;
+    const uint32_t *light_refs;
+    const uint8_t *texels;
+    const float *noise_vec;   /* n_noise * 256 * 4 */
+    const int32_t *noise_perm; /* n_noise * 3 * 256 */
+} rt_scene_desc;
+
+/* Outputs of Camera::build (camera.rs:280-366), computed on the host in f64. */
+typedef struct {
+    uint32_t image_width, image_height;
+    uint32_t sqrt_spp;     /* floor(sqrt(samples_per_px)), camera.rs:341 */
+    uint32_t max_depth;
+    uint32_t background_sky; /* 1 = Background::Sky (camera.rs:473-482), 0 = Constant */
+    uint32_t pad;
+    double background[3];
+    double center[3], pixel_00[3], pxdelta_u[3], pxdelta_v[3];
+    double defocus_angle;
+    double defocus_disk_u[3], defocus_disk_v[3];
+} rt_camera;
+
+#define RT_MODE_REF_EXACT 0u /* estimator exactly as shipped, camera.rs:455-470 */
+#define RT_MODE_BOOK3 1u     /* mixture estimator built from pdf.rs/onb.rs, specular bypass */
+
+#define RT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (see rt_stats) */
+typedef struct {
+    uint32_t mode;
+    uint32_t flags;
+    uint64_t seed;
+    uint32_t stratum_begin, stratum_end; /* stratum indices sj*sqrt_spp+si; end = 0 means sqrt_spp^2 */
+    uint32_t pool_size;                  /* rays in flight; 0 = default */
+    uint32_t pad;
+} rt_render_params;
+
+typedef struct {
+    uint64_t segments;     /* closest-hit queries issued (one world.hit at camera.rs:444 each) */
+    uint64_t camera_rays;
+    uint64_t dropped;      /* samples skipped because their pdf weight was not finite/positive */
+    uint64_t iterations;   /* wavefront iterations of the last rt_render */
+    uint64_t launches[4];  /* generate, extend, shade, other */
+    double kernel_ms[4];   /* summed HIP-event time per kernel class (RT_FLAG_TIME_KERNELS) */
+    double render_ms;      /* HIP-event time of the last rt_render, first launch to last */
+} rt_stats;
+
+typedef struct rt_handle rt_handle;
+
+/* ------------------------------------------------------------------ Part 1: device backend */
+int rt_device_count(int *n);
+int rt_create(int device_id, rt_handle **out);
+void rt_destroy(rt_handle *h);
+const char *rt_last_error(rt_handle *h); /* h may be NULL: error of the last failed rt_create */
+
+/* Run all kernels of this handle on an existing hipStream_t (NULL = the handle's own). */
+int rt_set_stream(rt_handle *h, void *hip_stream);
+int rt_synchronize(rt_handle *h);
+
+/* Copies the flat scene to HBM.  Replaces the Rc<dyn Hittable> graph handed to
+ * Camera::render (camera.rs:368). */
+int rt_upload_scene(rt_handle *h, const rt_scene_desc *scene);
+
+/* The pixel x stratum loop of camera.rs:386-401 for strata [begin,end): every sample's
+ * radiance is ADDED into the film (planar fp32 sums in HBM).  Asynchronous on the stream
+ * except for the completion polling it does itself; returns when all paths have finished. */
+int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *params);
+
+/* Film = 3 planes of width*height fp32 SUMS (R plane, G plane, B plane). */
+int rt_film_clear(rt_handle *h);
+int rt_film_resize(rt_handle *h, uint32_t width, uint32_t height); /* allocate + clear */
+int rt_film_bind(rt_handle *h, void *device_ptr, uint32_t width, uint32_t height); /* external */
+int rt_film_device_ptr(rt_handle *h, void **device_ptr, uint64_t *n_floats);
+/* rgb: width*height*3 interleaved, each = sum * scale (scale = 1/spp gives camera.rs:397) */
+int rt_film_download(rt_handle *h, float *rgb, float scale);
+int rt_get_stats(rt_handle *h, rt_stats *out);
+
+/* Parity hook: closest hit of the uploaded world for n host rays (o,d: n*3; time: n or NULL).
+ * prim = user-visible primitive id or -1.  ConstantMedium draws are keyed by ray index. */
+int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d, const float *time,
+                       float tmin, float tmax, int32_t *hit, int32_t *prim, float *t, float *u,
+                       float *v);
+/* Camera rays exactly as the generate kernel makes them (camera.rs:409-430). */
+int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *params, uint32_t n,
+                   const uint32_t *pixel, const uint32_t *stratum, float *o, float *d, float *time);
+/* Device-side unit hooks for the per-function parity tests. */
+int rt_eval_texture(rt_handle *h, uint32_t tex, uint32_t n, const float *uvp /* n*5: u v px py pz */,
+                    float *rgb);
+int rt_philox(rt_handle *h, uint32_t n, const uint32_t *ctr /* n*4 */, const uint32_t key[2],
+              uint32_t *out /* n*4 */);
+
+/* ------------------------------------------------------------------ Part 2: host scene layer */
+typedef struct rth_scene rth_scene;
+
+typedef struct { /* CameraBuilder (camera.rs:14-181) */
+    uint32_t image_width, image_height;
+    double vfov_deg;
+    uint32_t samples_per_px;
+    uint32_t max_depth;
+    int32_t background_sky;
+    double background[3];
+    double center[3], target[3], vup[3];
+    double defocus_angle_deg;
+    double focal_length;
+} rth_camera_builder;
+
+void rth_camera_defaults(rth_camera_builder *b); /* camera.rs:183-202 */
+/* with_aspect_ratio (camera.rs:78-92): sets width and round(width / aspect) */
+int rth_camera_with_aspect_ratio(rth_camera_builder *b, uint32_t width, double aspect_ratio);
+/* CameraBuilder::build + Camera::build.  On validation failure returns <0 and writes the
+ * newline-joined "CameraBuilder::..." messages (camera.rs:53-55) into err. */
+int rth_camera_build(const rth_camera_builder *b, rt_camera *out, char *err, uint32_t err_len);
+
+rth_scene *rth_scene_new(void);
+void rth_scene_free(rth_scene *);
+const char *rth_last_error(rth_scene *);
+
+int rth_tex_solid(rth_scene *, double r, double g, double b);
+int rth_tex_checker(rth_scene *, double scale, int even, int odd);
+int rth_tex_image(rth_scene *, uint32_t w, uint32_t h, const uint8_t *rgb);
+int rth_tex_image_png(rth_scene *, const char *path); /* 8-bit RGB PNG only (texture.rs:95-122) */
+int rth_tex_noise(rth_scene *, double scale, const double *ranvec, const int32_t *perm);
+
+int rth_mat_lambertian(rth_scene *, int tex);
+int rth_mat_light(rth_scene *, int tex);
+int rth_mat_metal(rth_scene *, double r, double g, double b, double fuzz);
+int rth_mat_dielectric(rth_scene *, double ior);
+int rth_mat_isotropic(rth_scene *, int tex);
+
+int rth_sphere(rth_scene *, const double c0[3], const double cv[3], double radius, int mat);
+int rth_quad(rth_scene *, int shape, const double q[3], const double u[3], const double v[3], int mat);
+int rth_box3(rth_scene *, const double a[3], const double b[3], int mat);
+int rth_list(rth_scene *, const int *objs, int n);
+int rth_bvh(rth_scene *, const int *objs, int n); /* BVHNode::new, boundingbox.rs:179-206 */
+int rth_translate(rth_scene *, int obj, const double off[3]);
+int rth_rotate_y(rth_scene *, int obj, double angle_rad);
+int rth_medium(rth_scene *, int boundary, double density, int tex);
+int rth_set_world(rth_scene *, int obj);
+int rth_set_lights(rth_scene *, int obj);
+int rth_prim_count(rth_scene *);
+
+/* ConfigModel::from_str + as_world (config.rs:628-706): parses the TOML text, adds its
+ * textures / materials / objects to the scene and returns the object id of the world
+ * HittableVec (>= 0), or < 0 with the message in rth_last_error. */
+int rth_load_toml(rth_scene *, const char *toml_text);
+int rth_list_add(rth_scene *, int list, int obj); /* HittableVec::add, hittable.rs:238-244 */
+int rth_material_by_name(rth_scene *, const char *name); /* materials loaded from TOML */
+
+/* Flatten world + lights into the arrays of rt_scene_desc (owned by the scene; valid until
+ * the next flatten or rth_scene_free). */
+int rth_flatten(rth_scene *, const rt_scene_desc **out);
+int rth_bvh_stats(rth_scene *, int obj, int *nodes, int *depth);
+
+/* Host-side pure functions kept for the reference's known-answer tests. */
+void rth_color_hex(uint32_t hex, double rgb[3]);                         /* color.rs:46-64 */
+void rth_color_quantize(const double rgb[3], int gamma, uint8_t out[3]); /* color.rs:130-155 */
+void rth_sphere_uv(const double p[3], double uv[2]);                     /* hittable.rs:150-162 */
+int rth_interval_contains(double a, double b, double x);
+int rth_interval_surrounds(double a, double b, double x);
+int rth_interval_overlap(double a0, double a1, double b0, double b1, double out[2]);
+void rth_interval_expand(double a, double b, double delta, double out[2]);
+double rth_interval_clamp(double a, double b, double x);
+/* ImageWriter (export.rs): 8-bit files from width*height*3 interleaved linear floats.
+ * PNG writes linear values, PPM applies gamma 2, both truncate (color.rs:148-155). */
+int rth_write_png(const char *path, uint32_t w, uint32_t h, const float *rgb);
+int rth_write_ppm(const char *path, uint32_t w, uint32_t h, const float *rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

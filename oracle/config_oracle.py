@@ -1,0 +1,197 @@
+"""Oracle-side restatement of the reference's TOML scene loader (config.rs), built on tomli.
+
+TEST INFRASTRUCTURE.  Follows config.rs rule by rule so that the product's own C++ loader
+(raytracing_amd/host/config.cpp) can be checked against an independent reading of the file:
+  * top-level `textures`, `materials`, `objects` are all mandatory           (config.rs:629-639)
+  * colours: "#hex" string or integer; <= 0xfff means three nibbles * 16      (config.rs:132-145, color.rs:46-64)
+  * material shortcuts SolidColor / ColoredLight(+brightness), fuzz > 1 => /100 (config.rs:403-465)
+  * objects: Sphere, Parallelogram (Disc / Triangle are todo!() in the reference; built here the
+    way hittable.rs:494-501, 596-619 construct them)
+"""
+import tomli
+
+
+class ConfigError(ValueError):
+    pass
+
+
+def color_hex(c):
+    if c <= 0xfff:
+        r, g, b = ((c & 0xf00) >> 8) * 16, (((c << 4) & 0xf00) >> 8) * 16, (((c << 8) & 0xf00) >> 8) * 16
+    else:
+        r, g, b = (c & 0xff0000) >> 16, ((c << 8) & 0xff0000) >> 16, ((c << 16) & 0xff0000) >> 16
+    return (r / 255.0, g / 255.0, b / 255.0)
+
+
+def parse_color(v, key):
+    if isinstance(v, str):
+        s = v.strip().strip("#")
+        try:
+            return color_hex(int(s, 16))
+        except ValueError as e:
+            raise ConfigError(f'Invalid hex string "{s}"') from e
+    if isinstance(v, bool) or not isinstance(v, int):
+        raise ConfigError(f"{key} must be a hex code or number.")
+    if v < 0 or v > 0xFFFFFFFF:
+        raise ConfigError(f"{key}: color integer out of range")
+    return color_hex(v)
+
+
+def floatlike(v, key):
+    if isinstance(v, bool) or not isinstance(v, (int, float)):
+        raise ConfigError(f"{key} must be a decimal number.")
+    return float(v)
+
+
+def vec3(v, key):
+    if not isinstance(v, list) or len(v) != 3:
+        raise ConfigError(f"{key} must be a valid 3D vector, represented as [x, y, z].")
+    return tuple(floatlike(x, f"{key}.{i}") for i, x in enumerate(v))
+
+
+def require(t, key, parent):
+    if key not in t:
+        raise ConfigError(f"{parent}.{key} must be provided.")
+    return t[key]
+
+
+def load(sb, text):
+    """Adds the file's textures/materials/objects to `sb`; returns (object ids, {name: material id})."""
+    cfg = tomli.loads(text)
+    for k, what in (("textures", "a table"), ("materials", "a table")):
+        if not isinstance(cfg.get(k), dict):
+            raise ConfigError(f"config.{k} must be {what}.")
+    if not isinstance(cfg.get("objects"), list):
+        raise ConfigError("config.objects must be a list of tables.")
+    textures, materials = {}, {}
+    for name in sorted(cfg["textures"]):  # toml::Table iterates in key order
+        t = cfg["textures"][name]
+        base = f"config.textures.{name}"
+        if not isinstance(t, dict):
+            raise ConfigError(f"{base} must be a table.")
+        ty = t.get("type")
+        if not isinstance(ty, str):
+            raise ConfigError(f"{base}.type must be a string.")
+        T = ty.upper()
+        if T in ("COLOR", "SOLIDCOLOR", "SOLID_COLOR"):
+            textures[name] = sb.tex_solid(*parse_color(require(t, "color", base), base + ".color"))
+        elif T in ("CHECKERBOARD", "CHECKER"):
+            scale = floatlike(require(t, "scale", base), base + ".scale")
+            arr = require(t, "textures", base)
+            if not isinstance(arr, list):
+                raise ConfigError(f"{base}.textures must be an array.")
+            if len(arr) != 2:
+                raise ConfigError(f"{base}.textures must be an array of length 2.")
+            a = sb.tex_solid(*parse_color(arr[0], base + ".textures.0"))
+            b = sb.tex_solid(*parse_color(arr[1], base + ".textures.1"))
+            textures[name] = sb.tex_checker(scale, a, b)
+        elif T == "IMAGE":
+            import numpy as np
+            from PIL import Image
+            path = require(t, "path", base)
+            im = Image.open(path)
+            if im.mode != "RGB":
+                raise ConfigError("Must be 8-bit PNG.")
+            textures[name] = sb.tex_image(np.asarray(im))
+        else:
+            raise ConfigError(f"{base}.type must be a valid texture type.")
+
+    def tex_by_name(v, key):
+        if not isinstance(v, str):
+            raise ConfigError(f"{key} must be a string representing a previously listed texture.")
+        if v not in textures:
+            raise ConfigError(f"{key} does not describe a valid texture.")
+        return textures[v]
+
+    for name in sorted(cfg["materials"]):
+        t = cfg["materials"][name]
+        base = f"config.materials.{name}"
+        if not isinstance(t, dict):
+            raise ConfigError(f"{base} must be a table.")
+        ty = t.get("type")
+        if not isinstance(ty, str):
+            raise ConfigError(f"{base}.type must be a string.")
+        T = ty.upper()
+        if T == "LAMBERTIAN":
+            materials[name] = sb.lambertian(tex_by_name(require(t, "texture", base), base + ".texture"))
+        elif T in ("METAL", "METALLIC", "FUZZY"):
+            albedo = parse_color(require(t, "albedo", base), base + ".albedo")
+            fuzz = floatlike(require(t, "fuzz", base), base + ".fuzz")
+            if fuzz > 1.0:
+                fuzz /= 100.0
+            if not (0.0 <= fuzz <= 1.0):
+                raise ConfigError("Invalid fuzz value (expected 0.0..=1.0)")
+            materials[name] = sb.metal(albedo, fuzz)
+        elif T in ("LIGHT", "LIGHTSOURCE", "DIFFUSELIGHT"):
+            materials[name] = sb.light(tex_by_name(require(t, "texture", base), base + ".texture"))
+        elif T == "DIELECTRIC":
+            materials[name] = sb.dielectric(floatlike(require(t, "refractive_index", base), base + ".refractive_index"))
+        elif T == "ISOTROPIC":
+            materials[name] = sb.isotropic(tex_by_name(require(t, "texture", base), base + ".texture"))
+        elif T == "SOLIDCOLOR":
+            c = parse_color(require(t, "color", base), base + ".color")
+            materials[name] = sb.lambertian(sb.tex_solid(*c))
+        elif T == "COLOREDLIGHT":
+            c = parse_color(require(t, "color", base), base + ".color")
+            if "brightness" in t:
+                k = floatlike(t["brightness"], base + ".brightness")
+                c = tuple(x * k for x in c)
+            materials[name] = sb.light(sb.tex_solid(*c))
+        else:
+            raise ConfigError(f"{base}.type must be a valid material type.")
+
+    def mat_by_name(v, key):
+        if not isinstance(v, str):
+            raise ConfigError(f"{key} must be a string representing a previously listed texture.")
+        if v not in materials:
+            raise ConfigError(f"{key} does not describe a valid texture.")
+        return materials[v]
+
+    objs = []
+    for i, t in enumerate(cfg["objects"]):
+        base = f"config.objects.{i}"
+        if not isinstance(t, dict):
+            raise ConfigError(f"{base} must be a table.")
+        ty = t.get("type")
+        if not isinstance(ty, str):
+            raise ConfigError(f"config.materials.{i}.type must be a string.")
+        T = ty.upper()
+
+        def two_vectors():
+            vecs = require(t, "vectors", base)
+            if not isinstance(vecs, list):
+                raise ConfigError(f"{base}.vectors must be an array.")
+            if len(vecs) != 2:
+                raise ConfigError(f"{base}.vectors must be an array of length 2.")
+            return vec3(vecs[0], base + ".vectors.0"), vec3(vecs[1], base + ".vectors.1")
+
+        if T == "SPHERE":
+            c = vec3(require(t, "center", base), base + ".center")
+            r = floatlike(require(t, "radius", base), base + ".radius")
+            objs.append(sb.sphere(c, r, mat_by_name(require(t, "material", base), base + ".material")))
+        elif T == "PARALLELOGRAM":
+            c = vec3(require(t, "corner", base), base + ".corner")
+            m = mat_by_name(require(t, "material", base), base + ".material")
+            u, v = two_vectors()
+            objs.append(sb.quad(c, u, v, m))
+        elif T == "DISC":
+            c = vec3(require(t, "center", base), base + ".center")
+            m = mat_by_name(require(t, "material", base), base + ".material")
+            u, v = two_vectors()
+            corner = tuple(c[k] - u[k] - v[k] for k in range(3))
+            objs.append(sb.quad(corner, tuple(2 * x for x in u), tuple(2 * x for x in v), m, shape=2))
+        elif T == "TRIANGLE":
+            pts = require(t, "points", base)
+            if not isinstance(pts, list) or len(pts) != 3:
+                raise ConfigError(f"{base}.points must be an array of length 3.")
+            m = mat_by_name(require(t, "material", base), base + ".material")
+            p = [vec3(x, f"{base}.points.{k}") for k, x in enumerate(pts)]
+            objs.append(sb.quad(p[0], tuple(p[1][k] - p[0][k] for k in range(3)),
+                                tuple(p[2][k] - p[0][k] for k in range(3)), m, shape=1))
+        else:
+            raise ConfigError(f"{base}.type must be a valid object type.")
+    return objs, materials
+
+
+def toml_objects(sb, text):
+    return load(sb, text)[0]

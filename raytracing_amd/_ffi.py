@@ -1,0 +1,163 @@
+"""ctypes binding of librt_amd.so (include/rt_amd.h).
+
+The library is the product: HIP kernels for gfx950 plus the C++ host scene layer.  There is
+no Python or CPU fallback; if the shared object is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "librt_amd.so"
+
+u32, u64, i32, f32, f64 = C.c_uint32, C.c_uint64, C.c_int32, C.c_float, C.c_double
+P = C.POINTER
+
+
+class RtNode(C.Structure):
+    _fields_ = [("lmin", f32 * 3), ("left", u32), ("lmax", f32 * 3), ("right", u32),
+                ("rmin", f32 * 3), ("count", u32), ("rmax", f32 * 3), ("pad", u32)]
+
+
+class RtQuad(C.Structure):
+    _fields_ = [("q", f32 * 3), ("d", f32), ("n", f32 * 3), ("area", f32), ("avec", f32 * 3), ("shape", u32),
+                ("bvec", f32 * 3), ("mat", u32), ("u", f32 * 3), ("prim_id", u32), ("v", f32 * 3), ("pad", u32)]
+
+
+class RtSphere(C.Structure):
+    _fields_ = [("c0", f32 * 3), ("radius", f32), ("cv", f32 * 3), ("mat", u32),
+                ("prim_id", u32), ("moving", u32), ("pad0", u32), ("pad1", u32)]
+
+
+class RtMedium(C.Structure):
+    _fields_ = [("first", u32), ("count", u32), ("neg_inv_density", f32), ("mat", u32),
+                ("prim_id", u32), ("pad0", u32), ("pad1", u32), ("pad2", u32)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("type", u32), ("tex", u32), ("albedo", f32 * 3), ("param", f32), ("needs_uv", u32), ("pad", u32)]
+
+
+class RtTexture(C.Structure):
+    _fields_ = [("type", u32), ("color", f32 * 3), ("scale", f32), ("a", u32), ("b", u32), ("offset", u32)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [("n_nodes", u32), ("n_refs", u32), ("n_quads", u32), ("n_spheres", u32), ("n_media", u32),
+                ("n_materials", u32), ("n_textures", u32), ("n_lights", u32), ("n_texel_bytes", u32),
+                ("n_noise", u32), ("root", u32), ("lights_kind", u32), ("n_prims", u32), ("max_stack", u32),
+                ("nodes", P(RtNode)), ("refs", P(u32)), ("quads", P(RtQuad)), ("spheres", P(RtSphere)),
+                ("media", P(RtMedium)), ("materials", P(RtMaterial)), ("textures", P(RtTexture)),
+                ("light_refs", P(u32)), ("texels", P(C.c_uint8)), ("noise_vec", P(f32)), ("noise_perm", P(i32))]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("image_width", u32), ("image_height", u32), ("sqrt_spp", u32), ("max_depth", u32),
+                ("background_sky", u32), ("pad", u32), ("background", f64 * 3), ("center", f64 * 3),
+                ("pixel_00", f64 * 3), ("pxdelta_u", f64 * 3), ("pxdelta_v", f64 * 3), ("defocus_angle", f64),
+                ("defocus_disk_u", f64 * 3), ("defocus_disk_v", f64 * 3)]
+
+
+class RtRenderParams(C.Structure):
+    _fields_ = [("mode", u32), ("flags", u32), ("seed", u64), ("stratum_begin", u32), ("stratum_end", u32),
+                ("pool_size", u32), ("pad", u32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("segments", u64), ("camera_rays", u64), ("dropped", u64), ("iterations", u64),
+                ("launches", u64 * 4), ("kernel_ms", f64 * 4), ("render_ms", f64)]
+
+
+class CameraBuilderStruct(C.Structure):
+    """Field layout shared by rth_camera_builder and the oracle's camera struct."""
+    _fields_ = [("image_width", u32), ("image_height", u32), ("vfov_deg", f64), ("samples_per_px", u32),
+                ("max_depth", u32), ("background_sky", i32), ("background", f64 * 3), ("center", f64 * 3),
+                ("target", f64 * 3), ("vup", f64 * 3), ("defocus_angle_deg", f64), ("focal_length", f64)]
+
+
+RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
+RT_FLAG_TIME_KERNELS = 1
+RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
+RT_NODE_LEAF = 0xFFFFFFFF
+
+# name -> (restype, argtypes); every symbol include/rt_amd.h declares
+_vp = C.c_void_p
+_d3 = P(f64)
+SIGNATURES = {
+    "rt_device_count": (C.c_int, [P(C.c_int)]),
+    "rt_create": (C.c_int, [C.c_int, P(_vp)]),
+    "rt_destroy": (None, [_vp]),
+    "rt_last_error": (C.c_char_p, [_vp]),
+    "rt_set_stream": (C.c_int, [_vp, _vp]),
+    "rt_synchronize": (C.c_int, [_vp]),
+    "rt_upload_scene": (C.c_int, [_vp, P(RtSceneDesc)]),
+    "rt_render": (C.c_int, [_vp, P(RtCamera), P(RtRenderParams)]),
+    "rt_film_clear": (C.c_int, [_vp]),
+    "rt_film_resize": (C.c_int, [_vp, u32, u32]),
+    "rt_film_bind": (C.c_int, [_vp, _vp, u32, u32]),
+    "rt_film_device_ptr": (C.c_int, [_vp, P(_vp), P(u64)]),
+    "rt_film_download": (C.c_int, [_vp, P(f32), f32]),
+    "rt_get_stats": (C.c_int, [_vp, P(RtStats)]),
+    "rt_intersect_batch": (C.c_int, [_vp, u32, P(f32), P(f32), P(f32), f32, f32, P(i32), P(i32), P(f32), P(f32), P(f32)]),
+    "rt_camera_rays": (C.c_int, [_vp, P(RtCamera), P(RtRenderParams), u32, P(u32), P(u32), P(f32), P(f32), P(f32)]),
+    "rt_eval_texture": (C.c_int, [_vp, u32, u32, P(f32), P(f32)]),
+    "rt_philox": (C.c_int, [_vp, u32, P(u32), P(u32), P(u32)]),
+    "rth_camera_defaults": (None, [P(CameraBuilderStruct)]),
+    "rth_camera_with_aspect_ratio": (C.c_int, [P(CameraBuilderStruct), u32, f64]),
+    "rth_camera_build": (C.c_int, [P(CameraBuilderStruct), P(RtCamera), C.c_char_p, u32]),
+    "rth_scene_new": (_vp, []),
+    "rth_scene_free": (None, [_vp]),
+    "rth_last_error": (C.c_char_p, [_vp]),
+    "rth_tex_solid": (C.c_int, [_vp, f64, f64, f64]),
+    "rth_tex_checker": (C.c_int, [_vp, f64, C.c_int, C.c_int]),
+    "rth_tex_image": (C.c_int, [_vp, u32, u32, P(C.c_uint8)]),
+    "rth_tex_image_png": (C.c_int, [_vp, C.c_char_p]),
+    "rth_tex_noise": (C.c_int, [_vp, f64, _d3, P(i32)]),
+    "rth_mat_lambertian": (C.c_int, [_vp, C.c_int]),
+    "rth_mat_light": (C.c_int, [_vp, C.c_int]),
+    "rth_mat_metal": (C.c_int, [_vp, f64, f64, f64, f64]),
+    "rth_mat_dielectric": (C.c_int, [_vp, f64]),
+    "rth_mat_isotropic": (C.c_int, [_vp, C.c_int]),
+    "rth_sphere": (C.c_int, [_vp, _d3, _d3, f64, C.c_int]),
+    "rth_quad": (C.c_int, [_vp, C.c_int, _d3, _d3, _d3, C.c_int]),
+    "rth_box3": (C.c_int, [_vp, _d3, _d3, C.c_int]),
+    "rth_list": (C.c_int, [_vp, P(C.c_int), C.c_int]),
+    "rth_bvh": (C.c_int, [_vp, P(C.c_int), C.c_int]),
+    "rth_translate": (C.c_int, [_vp, C.c_int, _d3]),
+    "rth_rotate_y": (C.c_int, [_vp, C.c_int, f64]),
+    "rth_medium": (C.c_int, [_vp, C.c_int, f64, C.c_int]),
+    "rth_set_world": (C.c_int, [_vp, C.c_int]),
+    "rth_set_lights": (C.c_int, [_vp, C.c_int]),
+    "rth_prim_count": (C.c_int, [_vp]),
+    "rth_load_toml": (C.c_int, [_vp, C.c_char_p]),
+    "rth_list_add": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "rth_material_by_name": (C.c_int, [_vp, C.c_char_p]),
+    "rth_flatten": (C.c_int, [_vp, P(P(RtSceneDesc))]),
+    "rth_bvh_stats": (C.c_int, [_vp, C.c_int, P(C.c_int), P(C.c_int)]),
+    "rth_color_hex": (None, [u32, _d3]),
+    "rth_color_quantize": (None, [_d3, C.c_int, P(C.c_uint8)]),
+    "rth_sphere_uv": (None, [_d3, _d3]),
+    "rth_interval_contains": (C.c_int, [f64, f64, f64]),
+    "rth_interval_surrounds": (C.c_int, [f64, f64, f64]),
+    "rth_interval_overlap": (C.c_int, [f64, f64, f64, f64, _d3]),
+    "rth_interval_expand": (None, [f64, f64, f64, _d3]),
+    "rth_interval_clamp": (f64, [f64, f64, f64]),
+    "rth_write_png": (C.c_int, [C.c_char_p, u32, u32, P(f32)]),
+    "rth_write_ppm": (C.c_int, [C.c_char_p, u32, u32, P(f32)]),
+}
+
+
+def load_library(path=None):
+    path = Path(path) if path else _LIB_PATH
+    if not path.exists():
+        raise ImportError(
+            f"{path} is missing: build it with `make` at the repository root "
+            "(hipcc --offload-arch=gfx950).  raytracing_amd has no CPU or pure-Python path.")
+    lib = C.CDLL(os.fspath(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the build is stale
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load_library()

@@ -1,0 +1,728 @@
+// rt_device.hip -- device half of the C ABI (rt_* in include/rt_amd.h): scene upload,
+// the wavefront render loop, film handling and the parity hooks.
+#include "rt_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int cls;
+};
+
+} // namespace
+
+struct rt_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // scene
+    std::vector<void *> scene_allocs;
+    DScene sc{};
+    bool have_scene = false;
+    bool flat = false;
+    uint32_t flat_first = 0, flat_count = 0, has_media = 0, n_prims = 0;
+    bool has_specular = false;
+    uint32_t n_textures = 0;
+
+    // queue
+    Queue q{};
+    size_t q_slots = 0;
+    Ctrl *d_ctrl = nullptr;
+    Ctrl *h_ctrl = nullptr; // pinned, two slots
+
+    // film
+    float *film = nullptr;
+    bool film_owned = false;
+    uint32_t film_w = 0, film_h = 0;
+
+    // stats
+    rt_stats stats{};
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_poll[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+int fail(rt_handle *h, const std::string &msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return -1;
+}
+
+#define RT_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(h, std::string(#call) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+template <typename T> int upload(rt_handle *h, const T *src, size_t n, const T **dst) {
+    *dst = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    void *p = nullptr;
+    RT_HIP(hipMalloc(&p, bytes));
+    h->scene_allocs.push_back(p);
+    if (n) RT_HIP(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    else RT_HIP(hipMemsetAsync(p, 0, bytes, h->stream));
+    *dst = static_cast<const T *>(p);
+    return 0;
+}
+
+void free_scene(rt_handle *h) {
+    for (void *p : h->scene_allocs) (void)hipFree(p);
+    h->scene_allocs.clear();
+    h->have_scene = false;
+}
+
+void free_queue(rt_handle *h) {
+    void *ptrs[] = {h->q.ra, h->q.rb, h->q.sa, h->q.sb, h->q.hit, h->q.count, h->q.gen_base, h->q.gen_n};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    h->q = Queue{};
+    h->q_slots = 0;
+}
+
+bool ref_ok(const rt_scene_desc *s, uint32_t r, bool allow_node, bool allow_medium) {
+    uint32_t kind = r >> RT_REF_KIND_SHIFT, idx = r & RT_REF_INDEX_MASK;
+    switch (kind) {
+    case RT_KIND_NODE: return allow_node && idx < s->n_nodes;
+    case RT_KIND_QUAD: return idx < s->n_quads;
+    case RT_KIND_SPHERE: return idx < s->n_spheres;
+    case RT_KIND_MEDIUM: return allow_medium && idx < s->n_media;
+    default: return false;
+    }
+}
+
+// Everything the kernels index with is checked here, once, on the host.
+int validate_scene(rt_handle *h, const rt_scene_desc *s) {
+    if (!s) return fail(h, "rt_upload_scene: null scene");
+    if ((s->n_nodes && !s->nodes) || (s->n_refs && !s->refs) || (s->n_quads && !s->quads) ||
+        (s->n_spheres && !s->spheres) || (s->n_media && !s->media) || (s->n_materials && !s->materials) ||
+        (s->n_textures && !s->textures) || (s->n_lights && !s->light_refs) || (s->n_texel_bytes && !s->texels) ||
+        (s->n_noise && (!s->noise_vec || !s->noise_perm)))
+        return fail(h, "rt_upload_scene: null array with non-zero count");
+    if (s->n_materials == 0) return fail(h, "rt_upload_scene: scene has no materials");
+    if (!ref_ok(s, s->root, true, true)) return fail(h, "rt_upload_scene: root reference out of range");
+    if (s->max_stack > uint32_t(STACK_DEPTH))
+        return fail(h, "rt_upload_scene: scene needs a deeper traversal stack than the kernels provide (" +
+                           std::to_string(s->max_stack) + " > " + std::to_string(STACK_DEPTH) + ")");
+    for (uint32_t i = 0; i < s->n_nodes; ++i) {
+        const rt_node &n = s->nodes[i];
+        if (n.right == RT_NODE_LEAF) {
+            if (uint64_t(n.left) + n.count > s->n_refs) return fail(h, "rt_upload_scene: leaf range outside refs");
+        } else {
+            if (!ref_ok(s, n.left, true, true) || !ref_ok(s, n.right, true, true))
+                return fail(h, "rt_upload_scene: node child out of range");
+            // a child index must point forward, or traversal could loop
+            for (uint32_t c : {n.left, n.right})
+                if ((c >> RT_REF_KIND_SHIFT) == RT_KIND_NODE && (c & RT_REF_INDEX_MASK) <= i)
+                    return fail(h, "rt_upload_scene: node child does not point forward");
+        }
+    }
+    for (uint32_t i = 0; i < s->n_refs; ++i) {
+        if (!ref_ok(s, s->refs[i], true, true)) return fail(h, "rt_upload_scene: ref out of range");
+    }
+    // leaf entries that are nodes must point forward as well
+    for (uint32_t i = 0; i < s->n_nodes; ++i) {
+        const rt_node &n = s->nodes[i];
+        if (n.right != RT_NODE_LEAF) continue;
+        for (uint32_t k = 0; k < n.count; ++k) {
+            uint32_t c = s->refs[n.left + k];
+            if ((c >> RT_REF_KIND_SHIFT) == RT_KIND_NODE && (c & RT_REF_INDEX_MASK) <= i)
+                return fail(h, "rt_upload_scene: list entry does not point forward");
+        }
+    }
+    for (uint32_t i = 0; i < s->n_quads; ++i) {
+        if (s->quads[i].mat >= s->n_materials) return fail(h, "rt_upload_scene: quad material out of range");
+        if (s->quads[i].shape > RT_SHAPE_DISC) return fail(h, "rt_upload_scene: bad quad shape");
+    }
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        if (s->spheres[i].mat >= s->n_materials) return fail(h, "rt_upload_scene: sphere material out of range");
+        if (!(s->spheres[i].radius > 0.f)) return fail(h, "rt_upload_scene: sphere radius must be > 0");
+    }
+    for (uint32_t i = 0; i < s->n_media; ++i) {
+        const rt_medium &m = s->media[i];
+        if (m.mat >= s->n_materials) return fail(h, "rt_upload_scene: medium material out of range");
+        if (uint64_t(m.first) + m.count > s->n_refs || m.count == 0)
+            return fail(h, "rt_upload_scene: medium boundary outside refs");
+        for (uint32_t k = 0; k < m.count; ++k)
+            if (!ref_ok(s, s->refs[m.first + k], false, false))
+                return fail(h, "rt_upload_scene: medium boundary must be quads/spheres");
+    }
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const rt_material &m = s->materials[i];
+        if (m.type > RT_MAT_ISOTROPIC) return fail(h, "rt_upload_scene: bad material type");
+        bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LIGHT || m.type == RT_MAT_ISOTROPIC;
+        if (textured && m.tex >= s->n_textures) return fail(h, "rt_upload_scene: material texture out of range");
+    }
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const rt_texture &t = s->textures[i];
+        if (t.type > RT_TEX_NOISE) return fail(h, "rt_upload_scene: bad texture type");
+        if (t.type == RT_TEX_CHECKER) {
+            // children must have smaller ids (they exist before their parent), so chains end
+            if (t.a >= i || t.b >= i) return fail(h, "rt_upload_scene: checker child must precede it");
+        }
+        if (t.type == RT_TEX_IMAGE) {
+            if (t.a == 0 || t.b == 0 || uint64_t(t.offset) + uint64_t(t.a) * t.b * 3 > s->n_texel_bytes)
+                return fail(h, "rt_upload_scene: image texture outside texel buffer");
+        }
+        if (t.type == RT_TEX_NOISE && t.offset >= s->n_noise)
+            return fail(h, "rt_upload_scene: noise table out of range");
+    }
+    if (s->n_noise)
+        for (size_t i = 0; i < size_t(s->n_noise) * 768; ++i)
+            if (s->noise_perm[i] < 0 || s->noise_perm[i] > 255)
+                return fail(h, "rt_upload_scene: noise permutation entry outside 0..255");
+    if ((s->lights_kind == RT_LIGHTS_NONE) != (s->n_lights == 0) || s->lights_kind > RT_LIGHTS_LIST)
+        return fail(h, "rt_upload_scene: lights_kind does not match n_lights");
+    if (s->lights_kind == RT_LIGHTS_SINGLE && s->n_lights != 1)
+        return fail(h, "rt_upload_scene: single light needs n_lights == 1");
+    for (uint32_t i = 0; i < s->n_lights; ++i)
+        if (!ref_ok(s, s->light_refs[i], false, false)) return fail(h, "rt_upload_scene: light must be a quad or sphere");
+    return 0;
+}
+
+int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCamera *out, uint32_t *se) {
+    if (!c || !p) return fail(h, "null camera or params");
+    if (c->image_width < 1 || c->image_height < 1) return fail(h, "camera: empty image");
+    if (uint64_t(c->image_width) * c->image_height > (1ull << 28)) return fail(h, "camera: image too large");
+    if (c->sqrt_spp < 1 || c->sqrt_spp > 4096) return fail(h, "camera: sqrt_spp must be in 1..4096");
+    if (c->max_depth < 1 || c->max_depth > 0xFFFFFFu) return fail(h, "camera: max_depth must be at least 1");
+    uint32_t spp = c->sqrt_spp * c->sqrt_spp;
+    uint32_t sb = p->stratum_begin, e = p->stratum_end ? p->stratum_end : spp;
+    if (e > spp || sb > e) return fail(h, "params: stratum range outside 0..sqrt_spp^2");
+    DCamera d{};
+    auto f3 = [](const double *v) { return V3{float(v[0]), float(v[1]), float(v[2])}; };
+    double rel[3];
+    for (int i = 0; i < 3; ++i) rel[i] = c->pixel_00[i] - c->center[i]; // f64 difference, then fp32
+    d.p00_rel = f3(rel);
+    d.du = f3(c->pxdelta_u);
+    d.dv = f3(c->pxdelta_v);
+    d.center = f3(c->center);
+    d.disk_u = f3(c->defocus_disk_u);
+    d.disk_v = f3(c->defocus_disk_v);
+    d.bg = f3(c->background);
+    d.W = c->image_width;
+    d.H = c->image_height;
+    d.npix = d.W * d.H;
+    d.sqrt_spp = c->sqrt_spp;
+    d.inv_sqrt = float(1.0 / double(c->sqrt_spp));
+    d.stratum_begin = sb;
+    d.max_depth = c->max_depth;
+    d.defocus = !(c->defocus_angle <= 0.0); // camera.rs:422
+    d.sky = c->background_sky != 0;
+    *out = d;
+    *se = e;
+    return 0;
+}
+
+int ensure_queue(rt_handle *h, uint32_t n_chunks, uint32_t cap) {
+    size_t slots = size_t(n_chunks) * cap;
+    if (h->q_slots >= slots && h->q.n_chunks >= n_chunks && h->q.cap == cap) {
+        h->q.n_chunks = n_chunks;
+        return 0;
+    }
+    free_queue(h);
+    RT_HIP(hipMalloc((void **)&h->q.ra, slots * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&h->q.rb, slots * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&h->q.sa, slots * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&h->q.sb, slots * sizeof(uint2)));
+    RT_HIP(hipMalloc((void **)&h->q.hit, slots * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&h->q.count, n_chunks * sizeof(uint32_t)));
+    RT_HIP(hipMalloc((void **)&h->q.gen_base, n_chunks * sizeof(unsigned long long)));
+    RT_HIP(hipMalloc((void **)&h->q.gen_n, n_chunks * sizeof(uint32_t)));
+    h->q.cap = cap;
+    h->q.n_chunks = n_chunks;
+    h->q_slots = slots;
+    return 0;
+}
+
+int ensure_film(rt_handle *h, uint32_t w, uint32_t hgt) {
+    if (h->film && h->film_w == w && h->film_h == hgt) return 0;
+    if (h->film && !h->film_owned)
+        return fail(h, "film: bound film has different dimensions than the camera");
+    if (h->film) (void)hipFree(h->film);
+    h->film = nullptr;
+    size_t n = size_t(w) * hgt * 3;
+    RT_HIP(hipMalloc((void **)&h->film, n * sizeof(float)));
+    RT_HIP(hipMemsetAsync(h->film, 0, n * sizeof(float), h->stream));
+    h->film_owned = true;
+    h->film_w = w;
+    h->film_h = hgt;
+    return 0;
+}
+
+// timed launch helper
+struct Timer {
+    rt_handle *h;
+    bool on;
+    int begin(int cls) {
+        if (!on) return -1;
+        if (h->ev_used == h->ev_pool.size()) {
+            EventPair p{};
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
+            h->ev_pool.push_back(p);
+        }
+        int i = int(h->ev_used++);
+        h->ev_pool[i].cls = cls;
+        (void)hipEventRecord(h->ev_pool[i].a, h->stream);
+        return i;
+    }
+    void end(int i) {
+        if (i >= 0) (void)hipEventRecord(h->ev_pool[i].b, h->stream);
+    }
+};
+
+void drain_timers(rt_handle *h) {
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) == hipSuccess)
+            h->stats.kernel_ms[h->ev_pool[i].cls] += ms;
+    }
+    h->ev_used = 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_device_count(int *n) {
+    rt_handle *h = nullptr;
+    if (!n) return fail(h, "rt_device_count: null argument");
+    RT_HIP(hipGetDeviceCount(n));
+    return 0;
+}
+
+int rt_create(int device_id, rt_handle **out) {
+    rt_handle *h = nullptr;
+    if (!out) return fail(h, "rt_create: null argument");
+    *out = nullptr;
+    int n = 0;
+    RT_HIP(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(h, "rt_create: no HIP device visible; this backend has no CPU path");
+    if (device_id < 0 || device_id >= n) return fail(h, "rt_create: device id out of range");
+    RT_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(h, std::string("rt_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    rt_handle *nh = new rt_handle();
+    nh->device = device_id;
+    h = nh;
+    hipError_t e = hipStreamCreateWithFlags(&nh->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&nh->d_ctrl, sizeof(Ctrl));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&nh->h_ctrl, 2 * sizeof(Ctrl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreate(&nh->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&nh->ev_end);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&nh->ev_poll[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&nh->ev_poll[1], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
+        rt_destroy(nh);
+        return -1;
+    }
+    nh->own_stream = true;
+    *out = nh;
+    return 0;
+}
+
+void rt_destroy(rt_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_scene(h);
+    free_queue(h);
+    if (h->film && h->film_owned) (void)hipFree(h->film);
+    if (h->d_ctrl) (void)hipFree(h->d_ctrl);
+    if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
+    for (auto &p : h->ev_pool) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (hipEvent_t e : {h->ev_begin, h->ev_end, h->ev_poll[0], h->ev_poll[1]})
+        if (e) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char *rt_last_error(rt_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rt_set_stream(rt_handle *h, void *hip_stream) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    RT_HIP(hipStreamSynchronize(h->stream));
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    h->own_stream = false;
+    if (hip_stream) {
+        h->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        RT_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return 0;
+}
+
+int rt_synchronize(rt_handle *h) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    RT_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (validate_scene(h, s)) return -1;
+    RT_HIP(hipStreamSynchronize(h->stream));
+    free_scene(h);
+    DScene d{};
+    static_assert(sizeof(rt_quad) == 96 && sizeof(rt_sphere) == 48 && sizeof(rt_node) == 64, "record sizes");
+    static_assert(sizeof(rt_material) == 32 && sizeof(rt_texture) == 32 && sizeof(rt_medium) == 32, "record sizes");
+    const rt_quad *dq;
+    const rt_sphere *ds;
+    const float *dnv;
+    if (upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
+        upload(h, s->quads, s->n_quads, &dq) || upload(h, s->spheres, s->n_spheres, &ds) ||
+        upload(h, s->media, s->n_media, &d.media) || upload(h, s->materials, s->n_materials, &d.mats) ||
+        upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) ||
+        upload(h, s->texels, s->n_texel_bytes, &d.texels) || upload(h, s->noise_vec, size_t(s->n_noise) * 1024, &dnv) ||
+        upload(h, s->noise_perm, size_t(s->n_noise) * 768, &d.noise_perm)) {
+        free_scene(h);
+        return -1;
+    }
+    d.quads = reinterpret_cast<const float4 *>(dq);
+    d.spheres = reinterpret_cast<const float4 *>(ds);
+    d.noise_vec = reinterpret_cast<const float4 *>(dnv);
+    d.root = s->root;
+    d.n_lights = s->n_lights;
+    d.lights_kind = s->lights_kind;
+    d.n_nodes = s->n_nodes;
+    RT_HIP(hipStreamSynchronize(h->stream));
+    h->sc = d;
+    h->have_scene = true;
+    h->has_media = s->n_media ? 1u : 0u;
+    h->n_prims = s->n_prims;
+    h->n_textures = s->n_textures;
+    h->has_specular = false;
+    for (uint32_t i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].type == RT_MAT_METAL || s->materials[i].type == RT_MAT_DIELECTRIC) h->has_specular = true;
+    // A world that is one list of primitives takes the stack-free kernel.
+    h->flat = false;
+    h->flat_first = h->flat_count = 0;
+    uint32_t rk = s->root >> RT_REF_KIND_SHIFT, ri = s->root & RT_REF_INDEX_MASK;
+    if (rk == RT_KIND_NODE && s->nodes[ri].right == RT_NODE_LEAF) {
+        bool only_prims = true;
+        for (uint32_t k = 0; k < s->nodes[ri].count; ++k)
+            if ((s->refs[s->nodes[ri].left + k] >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) only_prims = false;
+        if (only_prims && s->nodes[ri].count <= 64) {
+            h->flat = true;
+            h->flat_first = s->nodes[ri].left;
+            h->flat_count = s->nodes[ri].count;
+        }
+    }
+    return 0;
+}
+
+int rt_film_clear(rt_handle *h) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!h->film) return 0;
+    RT_HIP(hipMemsetAsync(h->film, 0, size_t(h->film_w) * h->film_h * 3 * sizeof(float), h->stream));
+    return 0;
+}
+
+int rt_film_resize(rt_handle *h, uint32_t w, uint32_t hgt) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (w == 0 || hgt == 0) return fail(h, "rt_film_resize: empty film");
+    if (h->film && !h->film_owned) {
+        h->film = nullptr;
+        h->film_w = h->film_h = 0;
+    }
+    if (ensure_film(h, w, hgt)) return -1;
+    return rt_film_clear(h);
+}
+
+int rt_film_bind(rt_handle *h, void *device_ptr, uint32_t w, uint32_t hgt) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!device_ptr || w == 0 || hgt == 0) return fail(h, "rt_film_bind: null pointer or empty film");
+    if ((reinterpret_cast<uintptr_t>(device_ptr) & 3u) != 0) return fail(h, "rt_film_bind: pointer not 4-byte aligned");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, device_ptr) != hipSuccess || attr.type != hipMemoryTypeDevice)
+        return fail(h, "rt_film_bind: not a device pointer");
+    if (attr.device != h->device) return fail(h, "rt_film_bind: pointer lives on another device");
+    RT_HIP(hipStreamSynchronize(h->stream));
+    if (h->film && h->film_owned) (void)hipFree(h->film);
+    h->film = static_cast<float *>(device_ptr);
+    h->film_owned = false;
+    h->film_w = w;
+    h->film_h = hgt;
+    return 0;
+}
+
+int rt_film_device_ptr(rt_handle *h, void **device_ptr, uint64_t *n_floats) {
+    if (!h || !device_ptr || !n_floats) return -1;
+    *device_ptr = h->film;
+    *n_floats = uint64_t(h->film_w) * h->film_h * 3;
+    return 0;
+}
+
+int rt_film_download(rt_handle *h, float *rgb, float scale) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!h->film) return fail(h, "rt_film_download: no film");
+    if (!rgb) return fail(h, "rt_film_download: null destination");
+    uint32_t npix = h->film_w * h->film_h;
+    float *tmp = nullptr;
+    RT_HIP(hipMalloc((void **)&tmp, size_t(npix) * 3 * sizeof(float)));
+    k_film_pack<<<(npix + 255) / 256, 256, 0, h->stream>>>(h->film, h->film + npix, h->film + 2 * size_t(npix), npix, scale, tmp);
+    hipError_t e = hipMemcpyAsync(rgb, tmp, size_t(npix) * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(h, std::string("rt_film_download: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rt_get_stats(rt_handle *h, rt_stats *out) {
+    if (!h || !out) return -1;
+    *out = h->stats;
+    return 0;
+}
+
+int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!h->have_scene) return fail(h, "rt_render: no scene uploaded");
+    DCamera dc;
+    uint32_t stratum_end;
+    if (make_camera(h, cam, p, &dc, &stratum_end)) return -1;
+    if (p->mode > RT_MODE_BOOK3) return fail(h, "rt_render: unknown estimator mode");
+    if (p->mode == RT_MODE_REF_EXACT) {
+        // Mirrors the reference's panics: Metal/Dielectric scatter is todo!() (material.rs:128,179)
+        // and only Parallelogram implements pdf_value/random (hittable.rs:99-107, 377-395).
+        if (h->has_specular)
+            return fail(h, "rt_render: REF_EXACT cannot render Metal/Dielectric (the reference panics with todo!())");
+        if (h->sc.lights_kind != RT_LIGHTS_SINGLE)
+            return fail(h, "rt_render: REF_EXACT needs `lights` to be one Parallelogram (others are unimplemented!() in the reference)");
+    }
+    if (ensure_film(h, dc.W, dc.H)) return -1;
+
+    const unsigned long long total = (unsigned long long)dc.npix * (stratum_end - dc.stratum_begin);
+    std::memset(&h->stats, 0, sizeof(h->stats));
+    if (total == 0) return 0;
+
+    // pool geometry: chunks of 512 rays, one wave each
+    const uint32_t cap = 512;
+    unsigned long long pool = p->pool_size ? p->pool_size : (1ull << 22);
+    if (pool > (1ull << 26)) pool = 1ull << 26;
+    if (pool > total) pool = total;
+    uint32_t n_chunks = uint32_t((pool + cap - 1) / cap);
+    n_chunks = (n_chunks + 3u) & ~3u;
+    if (ensure_queue(h, n_chunks, cap)) return -1;
+
+    Ctrl init{};
+    init.total_samples = total;
+    h->h_ctrl[0] = init;
+    RT_HIP(hipMemcpyAsync(h->d_ctrl, &h->h_ctrl[0], sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+    RT_HIP(hipMemsetAsync(h->q.count, 0, n_chunks * sizeof(uint32_t), h->stream));
+    RT_HIP(hipStreamSynchronize(h->stream)); // h_ctrl[0] is reused below
+
+    const uint32_t k0 = uint32_t(p->seed), k1 = uint32_t(p->seed >> 32);
+    const Film film{h->film, h->film + dc.npix, h->film + 2 * size_t(dc.npix)};
+    const dim3 grid(n_chunks / (BLOCK / WAVE)), block(BLOCK);
+    Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
+
+    RT_HIP(hipEventRecord(h->ev_begin, h->stream));
+    const int ITERS_PER_POLL = 8;
+    int slot = 0;
+    bool pending[2] = {false, false};
+    bool done = false;
+    unsigned long long guard = 0;
+    const unsigned long long max_iters = total / (size_t(n_chunks) * cap) * (dc.max_depth + 1ull) + 4ull * dc.max_depth + 64;
+    while (!done) {
+        for (int it = 0; it < ITERS_PER_POLL; ++it) {
+            int e = tm.begin(3);
+            k_scan<<<1, 1024, 0, h->stream>>>(h->q, h->d_ctrl);
+            tm.end(e);
+            e = tm.begin(0);
+            k_generate<<<grid, block, 0, h->stream>>>(h->q, dc, k0, k1);
+            tm.end(e);
+            e = tm.begin(1);
+            if (h->flat)
+                k_extend<true><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, h->flat_first, h->flat_count, h->has_media);
+            else
+                k_extend<false><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, 0u, 0u, h->has_media);
+            tm.end(e);
+            e = tm.begin(2);
+            if (p->mode == RT_MODE_REF_EXACT)
+                k_shade<RT_MODE_REF_EXACT><<<grid, block, 0, h->stream>>>(h->q, h->sc, dc, film, k0, k1, h->d_ctrl);
+            else
+                k_shade<RT_MODE_BOOK3><<<grid, block, 0, h->stream>>>(h->q, h->sc, dc, film, k0, k1, h->d_ctrl);
+            tm.end(e);
+            h->stats.launches[0]++, h->stats.launches[1]++, h->stats.launches[2]++, h->stats.launches[3]++;
+        }
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipMemcpyAsync(&h->h_ctrl[slot], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+        RT_HIP(hipEventRecord(h->ev_poll[slot], h->stream));
+        pending[slot] = true;
+        // look at the previous batch while this one runs
+        int prev = slot ^ 1;
+        if (pending[prev]) {
+            RT_HIP(hipEventSynchronize(h->ev_poll[prev]));
+            pending[prev] = false;
+            if (h->h_ctrl[prev].active == 0 && h->h_ctrl[prev].next_sample == total) done = true;
+        }
+        slot ^= 1;
+        guard += ITERS_PER_POLL;
+        if (guard > max_iters) {
+            (void)hipStreamSynchronize(h->stream);
+            return fail(h, "rt_render: iteration bound exceeded (paths did not finish)");
+        }
+    }
+    RT_HIP(hipEventRecord(h->ev_end, h->stream));
+    RT_HIP(hipStreamSynchronize(h->stream));
+    // the batch enqueued last holds the final counters
+    Ctrl fin;
+    RT_HIP(hipMemcpy(&fin, h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    h->stats.segments = fin.segments;
+    h->stats.camera_rays = fin.camera_rays;
+    h->stats.dropped = fin.dropped;
+    h->stats.iterations = fin.iterations;
+    float ms = 0.f;
+    RT_HIP(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+    h->stats.render_ms = ms;
+    drain_timers(h);
+    return 0;
+}
+
+int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d, const float *time, float tmin,
+                       float tmax, int32_t *hit, int32_t *prim, float *t, float *u, float *v) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!h->have_scene) return fail(h, "rt_intersect_batch: no scene uploaded");
+    if (n == 0) return 0;
+    if (!o || !d || !hit || !prim || !t || !u || !v) return fail(h, "rt_intersect_batch: null array");
+    float *d_o = nullptr, *d_d = nullptr, *d_time = nullptr, *d_f = nullptr;
+    int *d_i = nullptr;
+    hipError_t e = hipMalloc((void **)&d_o, size_t(n) * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_d, size_t(n) * 3 * sizeof(float));
+    if (e == hipSuccess && time) e = hipMalloc((void **)&d_time, size_t(n) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_f, size_t(n) * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_i, size_t(n) * 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_o, o, size_t(n) * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, d, size_t(n) * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && time) e = hipMemcpyAsync(d_time, time, size_t(n) * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
+        if (h->flat)
+            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, tmin, tmax, h->flat_first,
+                                                                   h->flat_count, d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+        else
+            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, tmin, tmax, 0u, 0u, d_i,
+                                                                    d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hit, d_i, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(prim, d_i + n, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, d_f, size_t(n) * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(u, d_f + n, size_t(n) * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(v, d_f + 2 * size_t(n), size_t(n) * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    for (void *p : {(void *)d_o, (void *)d_d, (void *)d_time, (void *)d_f, (void *)d_i})
+        if (p) (void)hipFree(p);
+    if (e != hipSuccess) return fail(h, std::string("rt_intersect_batch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *p, uint32_t n, const uint32_t *pixel,
+                   const uint32_t *stratum, float *o, float *d, float *time) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    DCamera dc;
+    uint32_t se;
+    if (make_camera(h, cam, p, &dc, &se)) return -1;
+    if (n == 0) return 0;
+    if (!pixel || !stratum || !o || !d || !time) return fail(h, "rt_camera_rays: null array");
+    for (uint32_t i = 0; i < n; ++i)
+        if (pixel[i] >= dc.npix || stratum[i] >= dc.sqrt_spp * dc.sqrt_spp)
+            return fail(h, "rt_camera_rays: pixel or stratum out of range");
+    uint32_t *d_u = nullptr;
+    float *d_f = nullptr;
+    hipError_t e = hipMalloc((void **)&d_u, size_t(n) * 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_f, size_t(n) * 7 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_u, pixel, size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_u + n, stratum, size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        k_camera_rays<<<(n + 255) / 256, 256, 0, h->stream>>>(dc, uint32_t(p->seed), uint32_t(p->seed >> 32), n, d_u, d_u + n,
+                                                              d_f, d_f + 3 * size_t(n), d_f + 6 * size_t(n));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(o, d_f, size_t(n) * 12, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d, d_f + 3 * size_t(n), size_t(n) * 12, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(time, d_f + 6 * size_t(n), size_t(n) * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (d_u) (void)hipFree(d_u);
+    if (d_f) (void)hipFree(d_f);
+    if (e != hipSuccess) return fail(h, std::string("rt_camera_rays: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rt_eval_texture(rt_handle *h, uint32_t tex, uint32_t n, const float *uvp, float *rgb) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!h->have_scene) return fail(h, "rt_eval_texture: no scene uploaded");
+    if (tex >= h->n_textures) return fail(h, "rt_eval_texture: texture id out of range");
+    if (n == 0) return 0;
+    if (!uvp || !rgb) return fail(h, "rt_eval_texture: null array");
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, size_t(n) * 5 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, size_t(n) * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, uvp, size_t(n) * 20, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        k_eval_texture<<<(n + 255) / 256, 256, 0, h->stream>>>(h->sc, tex, n, d_in, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_out, size_t(n) * 12, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(h, std::string("rt_eval_texture: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rt_philox(rt_handle *h, uint32_t n, const uint32_t *ctr, const uint32_t key[2], uint32_t *out) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (n == 0) return 0;
+    if (!ctr || !key || !out) return fail(h, "rt_philox: null array");
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, size_t(n) * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, size_t(n) * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, ctr, size_t(n) * 16, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        k_philox<<<(n + 255) / 256, 256, 0, h->stream>>>(n, d_in, key[0], key[1], d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, size_t(n) * 16, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(h, std::string("rt_philox: ") + hipGetErrorString(e));
+    return 0;
+}
+
+} // extern "C"

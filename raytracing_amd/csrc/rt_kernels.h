@@ -1,0 +1,844 @@
+// rt_kernels.h -- wavefront path-tracing kernels for gfx950 (fp32).
+//
+// Replaces the body of Camera::render (camera.rs:386-401) and everything below it.
+//
+// Work layout: the ray pool is split into CHUNKS, one per wavefront.  A chunk holds up to
+// `cap` rays, dense at its front; its wave walks it in tiles of 64.  Because a wave owns its
+// chunk, stream compaction after shading is a ballot + mbcnt prefix inside the wave with no
+// atomics and no barriers, and survivors are written in place (writes never pass the tile
+// being read).  One iteration = scan -> generate -> extend -> shade:
+//   scan     : one block; prefix-sums the free slots of all chunks and hands each chunk a
+//              contiguous range of new (pixel, stratum) sample ids; bookkeeping counters.
+//   generate : camera rays (camera.rs:409-430) appended to each chunk.
+//   extend   : closest hit of the world (camera.rs:444).
+//   shade    : emission, material scatter, light sampling, PDF weights, throughput update,
+//              film accumulation (camera.rs:451-470), compaction of surviving rays.
+#pragma once
+#include "rt_math.h"
+#include "../../include/rt_amd.h"
+
+namespace rt {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;          // 4 waves = 4 chunks per block
+constexpr int STACK_DEPTH = 32;     // per-lane traversal stack entries (LDS)
+constexpr int LDS_NODES = 128;      // BVH nodes staged per block (8 KiB)
+
+struct DScene {
+    const rt_node *nodes;
+    const uint32_t *refs;
+    const float4 *quads;   // 6 float4 per quad
+    const float4 *spheres; // 3 float4 per sphere
+    const rt_medium *media;
+    const rt_material *mats;
+    const rt_texture *texs;
+    const uint32_t *light_refs;
+    const uint8_t *texels;
+    const float4 *noise_vec;
+    const int *noise_perm;
+    uint32_t root, n_lights, lights_kind, n_nodes;
+};
+
+struct DCamera {
+    V3 p00_rel, du, dv, center, disk_u, disk_v, bg;
+    uint32_t W, H, npix, sqrt_spp, stratum_begin, max_depth, defocus, sky;
+    float inv_sqrt;
+};
+
+struct Ctrl {
+    unsigned long long next_sample, total_samples, segments, camera_rays, dropped;
+    uint32_t active, iterations;
+};
+
+// Ray queue, SoA of 16-byte records so every access is one dwordx4 per lane.
+struct Queue {
+    float4 *ra;  // origin.xyz, time
+    float4 *rb;  // direction.xyz, ref of the primitive the ray leaves (bits)
+    float4 *sa;  // throughput.rgb, pixel (bits)
+    uint2 *sb;   // stratum, bounce
+    float4 *hit; // t, ref (bits), u, v
+    uint32_t *count;             // rays per chunk
+    unsigned long long *gen_base; // first new sample id per chunk
+    uint32_t *gen_n;             // new rays per chunk
+    uint32_t cap, n_chunks;
+};
+
+__device__ __forceinline__ uint32_t fbits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); }
+
+// ------------------------------------------------------------------ primitives
+struct Best {
+    float t;
+    uint32_t ref;
+    float u, v;
+};
+
+// Parallelogram / Triangle / Disc (hittable.rs:341-371, 520-551, 641-672).
+// t in [tlo, thi] closed (Interval::contains).
+__device__ __forceinline__ bool hit_quad(const float4 *__restrict__ Q, V3 o, V3 d, float tlo, float thi,
+                                         float &t, float &a, float &b) {
+    float4 q0 = Q[0], q1 = Q[1];
+    V3 n = mk(q1);
+    float denom = dot(n, d);
+    if (fabsf(denom) < 1e-8f) return false;
+    V3 qo = mk(q0) - o;
+    float tt = dot(n, qo) / denom; // (D - n.o)/denom with the subtraction done first
+    if (!(tt >= tlo && tt <= thi)) return false;
+    float4 q2 = Q[2], q3 = Q[3];
+    V3 ph = fma3(d, tt, -qo);
+    float alpha = dot(ph, mk(q2));
+    float beta = dot(ph, mk(q3));
+    uint32_t shape = fbits(q2.w);
+    bool inside;
+    if (shape == RT_SHAPE_PARALLELOGRAM) {
+        inside = (0.0f <= alpha && alpha <= 1.0f) && (0.0f <= beta && beta <= 1.0f);
+    } else if (shape == RT_SHAPE_TRIANGLE) {
+        inside = !(alpha < 0.0f || beta < 0.0f || (alpha + beta) > 1.0f);
+    } else {
+        float ac = fabsf(0.5f - alpha), bc = fabsf(0.5f - beta);
+        inside = !(alpha < 0.0f || beta < 0.0f || sqrtf(ac * ac + bc * bc) > 0.5f);
+    }
+    if (!inside) return false;
+    t = tt;
+    a = alpha;
+    b = beta;
+    return true;
+}
+
+// Sphere (hittable.rs:166-204).  Roots accepted in (tlo, thi) open (Interval::surrounds).
+// Same quadratic, evaluated about the point of closest approach so that fp32 keeps the
+// discriminant of large spheres: disc/a = r^2 - |oc - (h/a) d|^2.
+// from_self: the ray starts on this sphere, so one root is 0 by construction and the other
+// is 2h/a; the reference reaches the same root after rejecting |t| < 0.001.
+__device__ __forceinline__ bool hit_sphere(const float4 *__restrict__ S, V3 o, V3 d, float time, float tlo,
+                                           float thi, bool from_self, float &t) {
+    float4 s0 = S[0], s1 = S[1];
+    V3 center = fma3(mk(s1), time, mk(s0));
+    V3 oc = center - o;
+    float a = len2(d);
+    float h = dot(d, oc);
+    float inv_a = 1.0f / a;
+    float tc = h * inv_a;
+    V3 perp = fma3(d, -tc, oc);
+    float disc_a = fmaf(s0.w, s0.w, -len2(perp));
+    if (disc_a < 0.0f) return false;
+    float root;
+    if (from_self) {
+        root = 2.0f * tc;
+        if (!(tlo < root && root < thi)) return false;
+    } else {
+        float dt = sqrtf(disc_a * inv_a);
+        root = tc - dt;
+        if (!(tlo < root && root < thi)) {
+            root = tc + dt;
+            if (!(tlo < root && root < thi)) return false;
+        }
+    }
+    t = root;
+    return true;
+}
+
+// hittable.rs:150-162
+__device__ __forceinline__ void sphere_uv(V3 n, float &u, float &v) {
+    float theta = acosf(fminf(fmaxf(-n.y, -1.0f), 1.0f));
+    float phi = atan2f(-n.z, n.x) + RT_PI;
+    u = phi * (0.5f * RT_INV_PI);
+    v = theta * RT_INV_PI;
+}
+
+// closest boundary hit with t in (tlo, thi) for a ConstantMedium boundary list
+__device__ __forceinline__ bool hit_boundary(const DScene &sc, uint32_t first, uint32_t count, V3 o, V3 d,
+                                             float time, float tlo, float thi, float &tout) {
+    bool any = false;
+    float closest = thi;
+    for (uint32_t k = 0; k < count; ++k) {
+        uint32_t r = sc.refs[first + k];
+        uint32_t idx = r & RT_REF_INDEX_MASK;
+        float t, a, b;
+        if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
+            if (hit_quad(sc.quads + 6 * idx, o, d, tlo, closest, t, a, b)) {
+                closest = t;
+                any = true;
+            }
+        } else {
+            if (hit_sphere(sc.spheres + 3 * idx, o, d, time, tlo, closest, false, t)) {
+                closest = t;
+                any = true;
+            }
+        }
+    }
+    tout = closest;
+    return any;
+}
+
+struct RayCtx { // what a medium needs to draw its free-flight distance
+    uint32_t k0, k1, pixel, sample, bounce;
+};
+
+// ConstantMedium::hit (hittable.rs:847-886)
+__device__ __forceinline__ bool hit_medium(const DScene &sc, uint32_t idx, V3 o, V3 d, float time, float tlo,
+                                           float thi, const RayCtx &rc, float &tout) {
+    rt_medium m = sc.media[idx];
+    float t1, t2;
+    if (!hit_boundary(sc, m.first, m.count, o, d, time, -RT_INF, RT_INF, t1)) return false;
+    if (!hit_boundary(sc, m.first, m.count, o, d, time, t1 + 0.0001f, RT_INF, t2)) return false;
+    if (t1 < tlo) t1 = tlo;
+    if (t2 > thi) t2 = thi;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    float ray_len = sqrtf(len2(d));
+    float dist_inside = (t2 - t1) * ray_len;
+    float xi = medium_uniform(rc.k0, rc.k1, rc.pixel, rc.sample, rc.bounce, m.prim_id);
+    float hit_dist = m.neg_inv_density * logf(xi);
+    if (hit_dist > dist_inside) return false;
+    tout = t1 + hit_dist / ray_len;
+    return true;
+}
+
+__device__ __forceinline__ void test_prim(const DScene &sc, uint32_t r, V3 o, V3 d, float time, float tlo,
+                                          uint32_t origin_ref, const RayCtx &rc, Best &best) {
+    uint32_t kind = r >> RT_REF_KIND_SHIFT, idx = r & RT_REF_INDEX_MASK;
+    float t, a = 0.f, b = 0.f;
+    bool h;
+    if (kind == RT_KIND_QUAD) {
+        // a ray leaving a planar primitive cannot meet it again; the reference rejects the
+        // t ~ 0 root through its 0.001 lower bound, which fp32 at scene scale cannot resolve
+        if (r == origin_ref) return;
+        h = hit_quad(sc.quads + 6 * idx, o, d, tlo, best.t, t, a, b);
+    } else if (kind == RT_KIND_SPHERE) {
+        h = hit_sphere(sc.spheres + 3 * idx, o, d, time, tlo, best.t, r == origin_ref, t);
+    } else {
+        h = hit_medium(sc, idx, o, d, time, tlo, best.t, rc, t);
+    }
+    if (h) {
+        best.t = t;
+        best.ref = r;
+        best.u = a;
+        best.v = b;
+    }
+}
+
+// BoundingBox3::hit (boundingbox.rs:96-113) with a cached reciprocal direction; the box is
+// entered only if the overlap has positive size (touching rejects, as in the reference).
+__device__ __forceinline__ bool hit_box(const float *mn, const float *mx, V3 o, V3 inv, float tlo, float thi,
+                                        float &tnear) {
+    float x0 = (mn[0] - o.x) * inv.x, x1 = (mx[0] - o.x) * inv.x;
+    float y0 = (mn[1] - o.y) * inv.y, y1 = (mx[1] - o.y) * inv.y;
+    float z0 = (mn[2] - o.z) * inv.z, z1 = (mx[2] - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tlo));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), thi));
+    tnear = tn;
+    return tn < tf;
+}
+
+// Closest hit of the world.  `stack` is this lane's column of an LDS array [STACK_DEPTH][BLOCK];
+// `lnodes` the block's LDS copy of nodes[0 .. LDS_NODES).
+template <bool USE_LDS_NODES>
+__device__ __forceinline__ void traverse(const DScene &sc, V3 o, V3 d, float time, float tlo, float thi,
+                                         uint32_t origin_ref, const RayCtx &rc, uint32_t *stack,
+                                         const rt_node *lnodes, Best &best) {
+    best.t = thi;
+    best.ref = RT_REF_NONE;
+    best.u = best.v = 0.f;
+    V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    int sp = 0;
+    uint32_t cur = sc.root;
+    for (;;) {
+        if ((cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) {
+            uint32_t idx = cur & RT_REF_INDEX_MASK;
+            const rt_node *np = (USE_LDS_NODES && idx < LDS_NODES) ? (lnodes + idx) : (sc.nodes + idx);
+            const float4 *n4 = reinterpret_cast<const float4 *>(np);
+            float4 a = n4[0], b = n4[1], c = n4[2], e = n4[3];
+            uint32_t left = fbits(a.w), right = fbits(b.w);
+            if (right == RT_NODE_LEAF) {
+                uint32_t count = fbits(c.w);
+                for (uint32_t k = 0; k < count; ++k) {
+                    uint32_t r = sc.refs[left + k];
+                    if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) {
+                        if (sp < STACK_DEPTH) stack[(sp++) * BLOCK] = r;
+                    } else {
+                        test_prim(sc, r, o, d, time, tlo, origin_ref, rc, best);
+                    }
+                }
+            } else {
+                float lmn[3] = {a.x, a.y, a.z}, lmx[3] = {b.x, b.y, b.z};
+                float rmn[3] = {c.x, c.y, c.z}, rmx[3] = {e.x, e.y, e.z};
+                float tl, tr;
+                bool hl = hit_box(lmn, lmx, o, inv, tlo, best.t, tl);
+                bool hr = hit_box(rmn, rmx, o, inv, tlo, best.t, tr);
+                if (hl && hr) {
+                    // near child first; results do not depend on the order (closest hit)
+                    bool swap = tr < tl;
+                    uint32_t nearc = swap ? right : left, farc = swap ? left : right;
+                    if (sp < STACK_DEPTH) stack[(sp++) * BLOCK] = farc;
+                    cur = nearc;
+                    continue;
+                } else if (hl) {
+                    cur = left;
+                    continue;
+                } else if (hr) {
+                    cur = right;
+                    continue;
+                }
+            }
+        } else {
+            test_prim(sc, cur, o, d, time, tlo, origin_ref, rc, best);
+        }
+        if (sp == 0) break;
+        cur = stack[(--sp) * BLOCK];
+    }
+}
+
+// Flat world (a HittableVec of primitives, e.g. main.rs:30-69): the ref list is uniform
+// across the wave, so primitive records come through scalar loads and no stack is needed.
+__device__ __forceinline__ void scan_flat(const DScene &sc, uint32_t first, uint32_t count, V3 o, V3 d,
+                                          float time, float tlo, float thi, uint32_t origin_ref,
+                                          const RayCtx &rc, Best &best) {
+    best.t = thi;
+    best.ref = RT_REF_NONE;
+    best.u = best.v = 0.f;
+    for (uint32_t k = 0; k < count; ++k) {
+        uint32_t r = sc.refs[first + k];
+        test_prim(sc, r, o, d, time, tlo, origin_ref, rc, best);
+    }
+}
+
+// ------------------------------------------------------------------ textures (texture.rs)
+__device__ __forceinline__ float perlin_noise(const float4 *vec, const int *perm, V3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = int(fx), j = int(fy), k = int(fz);
+    float uu = u * u * (3.f - 2.f * u), vv = v * v * (3.f - 2.f * v), ww = w * w * (3.f - 2.f * w);
+    float accum = 0.f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                float4 c = vec[perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)]];
+                float wx = u - di, wy = v - dj, wz = w - dk;
+                accum += (di ? uu : 1.f - uu) * (dj ? vv : 1.f - vv) * (dk ? ww : 1.f - ww) *
+                         (c.x * wx + c.y * wy + c.z * wz);
+            }
+    return accum;
+}
+
+__device__ __forceinline__ V3 tex_value(const DScene &sc, uint32_t id, float u, float v, V3 p) {
+    // Checkerboard children are arbitrary textures (texture.rs:39-43): follow the chain
+    for (int depth = 0; depth < 16; ++depth) {
+        rt_texture t = sc.texs[id];
+        if (t.type == RT_TEX_SOLID) return {t.color[0], t.color[1], t.color[2]};
+        if (t.type == RT_TEX_CHECKER) { // texture.rs:59-72
+            int x = int(floorf(t.scale * p.x));
+            int y = int(floorf(t.scale * p.y));
+            int z = int(floorf(t.scale * p.z));
+            bool even = ((x + y + z) % 2) == 0;
+            id = even ? t.a : t.b;
+            continue;
+        }
+        if (t.type == RT_TEX_IMAGE) { // texture.rs:125-139, texel index clamped to the image
+            float uc = fminf(fmaxf(u, 0.f), 1.f);
+            float vc = 1.0f - fminf(fmaxf(v, 0.f), 1.f);
+            uint32_t i = uint32_t(uc * float(t.a));
+            uint32_t j = uint32_t(vc * float(t.b));
+            i = min(i, t.a - 1);
+            j = min(j, t.b - 1);
+            const uint8_t *px = sc.texels + t.offset + (size_t(j) * t.a + i) * 3;
+            const float s = 1.0f / 255.0f;
+            return {float(px[0]) * s, float(px[1]) * s, float(px[2]) * s};
+        }
+        // noise: marble of "The Next Week" ch.5 (no counterpart in the reference)
+        const float4 *vec = sc.noise_vec + size_t(t.offset) * 256;
+        const int *perm = sc.noise_perm + size_t(t.offset) * 768;
+        float accum = 0.f, weight = 1.f;
+        V3 q = p;
+        for (int k = 0; k < 7; ++k) {
+            accum += weight * perlin_noise(vec, perm, q);
+            weight *= 0.5f;
+            q = q * 2.0f;
+        }
+        float s = 0.5f * (1.0f + sinf(t.scale * p.z + 10.0f * fabsf(accum)));
+        return {s, s, s};
+    }
+    return {0.f, 0.f, 0.f};
+}
+
+// ------------------------------------------------------------------ lights (hittable.rs:377-395)
+// direction to a random point of light `r`, unnormalised (Parallelogram::random), or towards
+// the visible cap of a sphere
+__device__ __forceinline__ V3 light_random(const DScene &sc, uint32_t r, V3 p, Rng &rng) {
+    uint32_t idx = r & RT_REF_INDEX_MASK;
+    if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
+        const float4 *Q = sc.quads + 6 * idx;
+        float a = rng.next();
+        float b = rng.next();
+        V3 lp = fma3(mk(Q[5]), b, fma3(mk(Q[4]), a, mk(Q[0])));
+        return lp - p;
+    }
+    const float4 *S = sc.spheres + 3 * idx;
+    float4 s0 = S[0];
+    V3 dir = mk(s0) - p;
+    float dist2 = len2(dir);
+    ONB uvw(dir);
+    float r1 = rng.next();
+    float r2 = rng.next();
+    float z = 1.0f + r2 * (sqrtf(1.0f - s0.w * s0.w / dist2) - 1.0f);
+    float sn = __builtin_amdgcn_sinf(r1), cs = __builtin_amdgcn_cosf(r1);
+    float s = sqrtf(fmaxf(0.f, 1.0f - z * z));
+    return uvw.transform(V3{cs * s, sn * s, z});
+}
+
+// Parallelogram::pdf_value (hittable.rs:377-389) / sphere cone pdf
+__device__ __forceinline__ float light_pdf(const DScene &sc, uint32_t r, V3 p, V3 dir) {
+    uint32_t idx = r & RT_REF_INDEX_MASK;
+    if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
+        const float4 *Q = sc.quads + 6 * idx;
+        float t, a, b;
+        if (!hit_quad(Q, p, dir, 0.001f, RT_INF, t, a, b)) return 0.0f;
+        float4 q1 = Q[1];
+        float l2 = len2(dir);
+        float dist2 = t * t * l2;
+        float cosine = fabsf(dot(dir, mk(q1)) / sqrtf(l2));
+        return dist2 / (cosine * q1.w);
+    }
+    const float4 *S = sc.spheres + 3 * idx;
+    float t;
+    if (!hit_sphere(S, p, dir, 0.f, 0.001f, RT_INF, false, t)) return 0.0f;
+    float4 s0 = S[0];
+    float dist2 = len2(mk(s0) - p);
+    float cos_max = sqrtf(1.0f - s0.w * s0.w / dist2);
+    return 1.0f / (2.0f * RT_PI * (1.0f - cos_max));
+}
+
+__device__ __forceinline__ V3 lights_random(const DScene &sc, V3 p, Rng &rng) {
+    uint32_t r;
+    if (sc.lights_kind == RT_LIGHTS_LIST) {
+        uint32_t i = uint32_t(rng.next() * float(sc.n_lights));
+        r = sc.light_refs[min(i, sc.n_lights - 1)];
+    } else {
+        r = sc.light_refs[0];
+    }
+    return light_random(sc, r, p, rng);
+}
+__device__ __forceinline__ float lights_pdf(const DScene &sc, V3 p, V3 dir) {
+    if (sc.lights_kind != RT_LIGHTS_LIST) return light_pdf(sc, sc.light_refs[0], p, dir);
+    float w = 1.0f / float(sc.n_lights), sum = 0.f;
+    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += w * light_pdf(sc, sc.light_refs[i], p, dir);
+    return sum;
+}
+
+// ------------------------------------------------------------------ camera (camera.rs:409-430)
+__device__ __forceinline__ void camera_ray(const DCamera &cam, uint32_t pixel, uint32_t stratum, uint32_t k0,
+                                           uint32_t k1, V3 &o, V3 &d, float &time) {
+    uint32_t i = pixel % cam.W, j = pixel / cam.W;
+    uint32_t si = stratum % cam.sqrt_spp, sj = stratum / cam.sqrt_spp;
+    Rng rng;
+    rng.begin(k0, k1, pixel, stratum, STREAM_CAMERA, 0);
+    float ox = ((float(si) + rng.next()) * cam.inv_sqrt) - 0.5f;
+    float oy = ((float(sj) + rng.next()) * cam.inv_sqrt) - 0.5f;
+    // px_sample - camera_center, accumulated from small terms so the sub-pixel offset
+    // survives fp32 (pixel_00 itself sits at scene-scale coordinates)
+    V3 rel = fma3(cam.du, float(i), cam.p00_rel);
+    rel = fma3(cam.dv, float(j), rel);
+    rel = fma3(cam.du, ox, rel);
+    rel = fma3(cam.dv, oy, rel);
+    o = cam.center;
+    d = rel;
+    if (cam.defocus) { // camera.rs:484-488, two_d.rs:183-190
+        float px, py;
+        for (;;) {
+            px = rng.pm1();
+            py = rng.pm1();
+            if (px * px + py * py < 1.0f) break;
+        }
+        V3 off = px * cam.disk_u + py * cam.disk_v;
+        o = cam.center + off;
+        d = rel - off;
+    }
+    time = rng.next();
+}
+
+// ------------------------------------------------------------------ kernels
+
+// One block.  Exclusive prefix over the chunks' free slots -> sample ranges for generate.
+__global__ void __launch_bounds__(1024) k_scan(Queue q, Ctrl *ctrl) {
+    __shared__ uint32_t s_free[1024], s_alive[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (q.n_chunks + 1023u) / 1024u;
+    const uint32_t lo = tid * per, hi = min(lo + per, q.n_chunks);
+    uint32_t fsum = 0, asum = 0;
+    for (uint32_t w = lo; w < hi; ++w) {
+        uint32_t c = q.count[w];
+        asum += c;
+        fsum += q.cap - c;
+    }
+    s_free[tid] = fsum;
+    s_alive[tid] = asum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) { // inclusive Hillis-Steele scan
+        uint32_t f = 0, a = 0;
+        if (tid >= off) {
+            f = s_free[tid - off];
+            a = s_alive[tid - off];
+        }
+        __syncthreads();
+        s_free[tid] += f;
+        s_alive[tid] += a;
+        __syncthreads();
+    }
+    const unsigned long long next = ctrl->next_sample;
+    const unsigned long long remaining = ctrl->total_samples - next;
+    unsigned long long base = s_free[tid] - fsum; // exclusive prefix
+    for (uint32_t w = lo; w < hi; ++w) {
+        uint32_t fr = q.cap - q.count[w];
+        unsigned long long left = remaining > base ? remaining - base : 0ull;
+        uint32_t n = left < fr ? uint32_t(left) : fr;
+        q.gen_base[w] = next + base;
+        q.gen_n[w] = n;
+        base += fr;
+    }
+    __syncthreads();
+    if (tid == 1023) {
+        unsigned long long total_free = s_free[1023];
+        unsigned long long total_new = total_free < remaining ? total_free : remaining;
+        uint32_t active = s_alive[1023] + uint32_t(total_new);
+        ctrl->next_sample = next + total_new;
+        ctrl->active = active;
+        ctrl->segments += active;
+        ctrl->camera_rays += total_new;
+        ctrl->iterations += 1;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_generate(Queue q, DCamera cam, uint32_t k0, uint32_t k1) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t chunk = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x / WAVE);
+    if (chunk >= q.n_chunks) return;
+    const uint32_t n = q.gen_n[chunk];
+    if (n == 0) return;
+    const uint32_t have = q.count[chunk];
+    const unsigned long long gbase = q.gen_base[chunk];
+    const size_t cbase = size_t(chunk) * q.cap;
+    for (uint32_t k = lane; k < n; k += WAVE) {
+        unsigned long long g = gbase + k;
+        uint32_t pixel = uint32_t(g % cam.npix);
+        uint32_t stratum = cam.stratum_begin + uint32_t(g / cam.npix);
+        V3 o, d;
+        float time;
+        camera_ray(cam, pixel, stratum, k0, k1, o, d, time);
+        size_t s = cbase + have + k;
+        q.ra[s] = make_float4(o.x, o.y, o.z, time);
+        q.rb[s] = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
+        q.sa[s] = make_float4(1.f, 1.f, 1.f, bitsf(pixel));
+        q.sb[s] = make_uint2(stratum, 0u);
+    }
+    if (lane == 0) q.count[chunk] = have + n;
+}
+
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_extend(Queue q, DScene sc, uint32_t k0, uint32_t k1, uint32_t flat_first,
+                                                   uint32_t flat_count, uint32_t has_media) {
+    __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
+    __shared__ rt_node s_nodes[FLAT ? 1 : LDS_NODES];
+    if (!FLAT) { // stage the top of the BVH
+        const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
+        const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+        float4 *dst = reinterpret_cast<float4 *>(s_nodes);
+        for (uint32_t i = threadIdx.x; i < nn * 4; i += BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t chunk = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x / WAVE);
+    if (chunk >= q.n_chunks) return;
+    const uint32_t n = q.count[chunk];
+    const size_t cbase = size_t(chunk) * q.cap;
+    for (uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t k = base + lane;
+        if (k >= n) continue;
+        const size_t s = cbase + k;
+        float4 ra = q.ra[s], rb = q.rb[s];
+        V3 o = mk(ra), d = mk(rb);
+        RayCtx rc{k0, k1, 0u, 0u, 0u};
+        if (has_media) {
+            rc.pixel = fbits(q.sa[s].w);
+            uint2 sb = q.sb[s];
+            rc.sample = sb.x;
+            rc.bounce = sb.y;
+        }
+        Best best;
+        if (FLAT)
+            scan_flat(sc, flat_first, flat_count, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
+        else
+            traverse<true>(sc, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack + threadIdx.x, s_nodes, best);
+        q.hit[s] = make_float4(best.t, bitsf(best.ref), best.u, best.v);
+    }
+}
+
+struct Film {
+    float *r, *g, *b;
+};
+__device__ __forceinline__ void film_add(const Film &f, uint32_t pixel, V3 c) {
+    if (c.x != 0.f) atomicAdd(f.r + pixel, c.x);
+    if (c.y != 0.f) atomicAdd(f.g + pixel, c.y);
+    if (c.z != 0.f) atomicAdd(f.b + pixel, c.z);
+}
+
+// camera.rs:451-470 for one path vertex.  Returns true if the path continues.
+template <int MODE>
+__device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, const Film &film, uint32_t k0,
+                                          uint32_t k1, float4 &ra, float4 &rb, float4 &sa, uint2 &sb, float4 h,
+                                          Ctrl *ctrl) {
+    V3 o = mk(ra), d = mk(rb), thr = mk(sa);
+    const float time = ra.w;
+    const uint32_t pixel = fbits(sa.w);
+    const uint32_t ref = fbits(h.y);
+    if (ref == RT_REF_NONE) { // camera.rs:445-448, 473-482
+        V3 bg = cam.bg;
+        if (cam.sky) {
+            float a = 0.5f * (unit(d).y + 1.0f);
+            bg = (1.0f - a) * V3{1.f, 1.f, 1.f} + a * V3{0.5f, 0.7f, 1.0f};
+        }
+        film_add(film, pixel, thr * bg);
+        return false;
+    }
+    const float t = h.x;
+    V3 p = fma3(d, t, o);
+    const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+    V3 n;
+    uint32_t mat_id;
+    float u = h.z, v = h.w;
+    bool front = true;
+    if (kind == RT_KIND_QUAD) {
+        const float4 *Q = sc.quads + 6 * idx;
+        n = mk(Q[1]);
+        mat_id = fbits(Q[3].w);
+    } else if (kind == RT_KIND_SPHERE) {
+        const float4 *S = sc.spheres + 3 * idx;
+        float4 s0 = S[0], s1 = S[1];
+        V3 center = fma3(mk(s1), time, mk(s0));
+        n = (p - center) * (1.0f / s0.w);
+        mat_id = fbits(s1.w);
+    } else { // ConstantMedium: arbitrary normal, front face (hittable.rs:877-885)
+        n = {1.f, 0.f, 0.f};
+        mat_id = sc.media[idx].mat;
+    }
+    if (kind != RT_KIND_MEDIUM) { // HitRecord::from_incoming_ray (hittable.rs:59-79)
+        front = dot(d, n) < 0.0f;
+        if (!front) n = -n;
+    }
+    const rt_material m = sc.mats[mat_id];
+    if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u, v);
+
+    if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
+        if (front) film_add(film, pixel, thr * tex_value(sc, m.tex, u, v, p));
+        return false;
+    }
+    const uint32_t bounce = sb.y;
+    Rng rng;
+    rng.begin(k0, k1, pixel, sb.x, STREAM_SHADE, bounce);
+    V3 dir, att;
+    float weight = 1.0f;
+
+    if (m.type == RT_MAT_METAL) { // material.rs:115-131 (specular: attenuation * L(reflected))
+        V3 refl = d - n * (2.0f * dot(d, n));
+        dir = unit(refl);
+        if (m.param > 0.f) dir = dir + m.param * random_in_unit_sphere(rng);
+        if (dot(dir, n) < 0.0f) return false;
+        att = {m.albedo[0], m.albedo[1], m.albedo[2]};
+    } else if (m.type == RT_MAT_DIELECTRIC) { // material.rs:154-182, vec.rs:289-295
+        float ri = front ? 1.0f / m.param : m.param;
+        V3 ud = unit(d);
+        float cos_theta = fminf(-dot(ud, n), 1.0f);
+        float sin_theta = sqrtf(fmaxf(0.f, 1.0f - cos_theta * cos_theta));
+        bool reflect_it = ri * sin_theta > 1.0f;
+        if (!reflect_it) {
+            float r0 = (1.0f - ri) / (1.0f + ri);
+            r0 = r0 * r0;
+            float x = 1.0f - cos_theta;
+            float x2 = x * x;
+            reflect_it = (r0 + (1.0f - r0) * x2 * x2 * x) > rng.next();
+        }
+        if (reflect_it) {
+            dir = ud - n * (2.0f * dot(ud, n));
+        } else {
+            V3 perp = ri * (ud + cos_theta * n);
+            V3 par = n * (-sqrtf(fabsf(1.0f - len2(perp))));
+            dir = perp + par;
+        }
+        att = {1.f, 1.f, 1.f};
+    } else {
+        // Lambertian (material.rs:45-63) or Isotropic (material.rs:198-212)
+        const bool iso = m.type == RT_MAT_ISOTROPIC;
+        att = tex_value(sc, m.tex, u, v, p);
+        float spdf, pdf;
+        if (MODE == RT_MODE_REF_EXACT) {
+            // Shipped estimator: the material's own sample only feeds scattering_pdf
+            // (camera.rs:464); the traced direction comes from the light (camera.rs:460-462).
+            if (iso) {
+                (void)random_in_unit_sphere(rng);
+                spdf = 0.25f * RT_INV_PI;
+            } else {
+                (void)rng.next(); // r1: azimuth of the discarded cosine sample
+                float r2 = rng.next();
+                // n . unit(onb.transform(cosine sample)) = sqrt(1-r2)
+                spdf = fmaxf(0.f, sqrtf(1.0f - r2) * RT_INV_PI);
+            }
+            dir = lights_random(sc, p, rng);
+            pdf = lights_pdf(sc, p, dir);
+        } else {
+            // 0.5 light list + 0.5 material PDF (pdf.rs:62-90), intended branch order
+            ONB uvw(n);
+            bool pick_light = false;
+            if (sc.lights_kind != RT_LIGHTS_NONE) pick_light = rng.next() < 0.5f;
+            if (pick_light) {
+                dir = lights_random(sc, p, rng);
+            } else if (iso) {
+                dir = random_in_unit_sphere(rng);
+            } else {
+                float r1 = rng.next();
+                float r2 = rng.next();
+                float sr = sqrtf(r2);
+                dir = uvw.transform(V3{__builtin_amdgcn_cosf(r1) * sr, __builtin_amdgcn_sinf(r1) * sr,
+                                       sqrtf(1.0f - r2)});
+            }
+            float inv_len = 1.0f / sqrtf(len2(dir));
+            float cosn = dot(dir, uvw.w) * inv_len;
+            float mpdf = iso ? 0.25f * RT_INV_PI : fmaxf(0.f, cosn * RT_INV_PI);
+            spdf = mpdf; // Lambertian::scattering_pdf == CosinePDF::value; Isotropic likewise
+            pdf = sc.lights_kind != RT_LIGHTS_NONE ? 0.5f * lights_pdf(sc, p, dir) + 0.5f * mpdf : mpdf;
+        }
+        weight = spdf / pdf;
+        if (!(pdf > 0.0f) || !(fabsf(weight) <= 3.0e38f)) { // would be inf/NaN radiance
+            atomicAdd(&ctrl->dropped, 1ull);
+            return false;
+        }
+        if (weight == 0.0f) return false; // the sample carries nothing further
+    }
+    if (bounce + 1 >= cam.max_depth) return false; // depth == 0 -> black (camera.rs:439-442)
+    thr = thr * att * weight;
+    ra = make_float4(p.x, p.y, p.z, time);
+    rb = make_float4(dir.x, dir.y, dir.z, bitsf(ref));
+    sa = make_float4(thr.x, thr.y, thr.z, sa.w);
+    sb.y = bounce + 1;
+    return true;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_shade(Queue q, DScene sc, DCamera cam, Film film, uint32_t k0,
+                                                  uint32_t k1, Ctrl *ctrl) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t chunk = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x / WAVE);
+    if (chunk >= q.n_chunks) return;
+    const uint32_t n = q.count[chunk];
+    if (n == 0) return;
+    const size_t cbase = size_t(chunk) * q.cap;
+    uint32_t out = 0; // survivors written so far; always <= base, so writes never pass reads
+    for (uint32_t base = 0; base < n; base += WAVE) {
+        const uint32_t k = base + lane;
+        bool alive = false;
+        float4 ra, rb, sa;
+        uint2 sb;
+        if (k < n) {
+            const size_t s = cbase + k;
+            ra = q.ra[s];
+            rb = q.rb[s];
+            sa = q.sa[s];
+            sb = q.sb[s];
+            float4 h = q.hit[s];
+            alive = shade_one<MODE>(sc, cam, film, k0, k1, ra, rb, sa, sb, h, ctrl);
+        }
+        // wave-level stream compaction: ballot + mbcnt prefix
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+        if (alive) {
+            const size_t s = cbase + out + prefix;
+            q.ra[s] = ra;
+            q.rb[s] = rb;
+            q.sa[s] = sa;
+            q.sb[s] = sb;
+        }
+        out += uint32_t(__popcll(mask));
+    }
+    if (lane == 0) q.count[chunk] = out;
+}
+
+// ------------------------------------------------------------------ hooks
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n, const float *o3, const float *d3,
+                                                            const float *time, float tmin, float tmax,
+                                                            uint32_t flat_first, uint32_t flat_count, int *hit,
+                                                            int *prim, float *t, float *u, float *v) {
+    __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    V3 o = {o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d = {d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
+    float tm = time ? time[i] : 0.f;
+    RayCtx rc{0u, 0u, i, 0u, 0u};
+    Best best;
+    if (FLAT)
+        scan_flat(sc, flat_first, flat_count, o, d, tm, tmin, tmax, RT_REF_NONE, rc, best);
+    else
+        traverse<false>(sc, o, d, tm, tmin, tmax, RT_REF_NONE, rc, s_stack + threadIdx.x, nullptr, best);
+    int pid = -1;
+    float uu = best.u, vv = best.v;
+    if (best.ref != RT_REF_NONE) {
+        uint32_t kind = best.ref >> RT_REF_KIND_SHIFT, idx = best.ref & RT_REF_INDEX_MASK;
+        if (kind == RT_KIND_QUAD) {
+            pid = int(fbits(sc.quads[6 * idx + 4].w));
+        } else if (kind == RT_KIND_SPHERE) {
+            const float4 *S = sc.spheres + 3 * idx;
+            float4 s0 = S[0], s1 = S[1], s2 = S[2];
+            pid = int(fbits(s2.x));
+            V3 center = fma3(mk(s1), tm, mk(s0));
+            V3 nn = (fma3(d, best.t, o) - center) * (1.0f / s0.w);
+            sphere_uv(nn, uu, vv);
+        } else {
+            pid = int(sc.media[idx].prim_id);
+            uu = vv = __builtin_nanf("");
+        }
+    }
+    hit[i] = best.ref != RT_REF_NONE;
+    prim[i] = pid;
+    t[i] = best.ref != RT_REF_NONE ? best.t : RT_INF;
+    u[i] = uu;
+    v[i] = vv;
+}
+
+__global__ void k_camera_rays(DCamera cam, uint32_t k0, uint32_t k1, uint32_t n, const uint32_t *pixel,
+                              const uint32_t *stratum, float *o3, float *d3, float *time) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d;
+    float tm;
+    camera_ray(cam, pixel[i], stratum[i], k0, k1, o, d, tm);
+    o3[3 * i] = o.x, o3[3 * i + 1] = o.y, o3[3 * i + 2] = o.z;
+    d3[3 * i] = d.x, d3[3 * i + 1] = d.y, d3[3 * i + 2] = d.z;
+    time[i] = tm;
+}
+
+__global__ void k_eval_texture(DScene sc, uint32_t tex, uint32_t n, const float *uvp, float *rgb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 c = tex_value(sc, tex, uvp[5 * i], uvp[5 * i + 1], V3{uvp[5 * i + 2], uvp[5 * i + 3], uvp[5 * i + 4]});
+    rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+}
+
+__global__ void k_philox(uint32_t n, const uint32_t *ctr, uint32_t k0, uint32_t k1, uint32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t o[4];
+    philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], k0, k1, o);
+    for (int k = 0; k < 4; ++k) out[4 * i + k] = o[k];
+}
+
+// film planes -> interleaved rgb * scale
+__global__ void k_film_pack(const float *r, const float *g, const float *b, uint32_t npix, float scale, float *rgb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    rgb[3 * i] = r[i] * scale;
+    rgb[3 * i + 1] = g[i] * scale;
+    rgb[3 * i + 2] = b[i] * scale;
+}
+
+} // namespace rt
