@@ -73,12 +73,17 @@ typedef struct {
     uint32_t pad;
 } rt_quad;
 
-/* Sphere, 48 B (hittable.rs:117-209): centre(time) = c0 + time * cv */
+/* Sphere, 48 B (hittable.rs:117-209): centre(time) = c0 + time * cv.
+ * u_shift: a sphere under RotateY keeps the texture longitude of its own frame
+ * (Sphere::get_uv runs before the normal is rotated back, hittable.rs:194, 801-805), so
+ * u = frac(u_world + u_shift) with u_shift = -angle / 2pi of the baked rotation. */
 typedef struct {
     float c0[3], radius;
     float cv[3];
     uint32_t mat;
-    uint32_t prim_id, moving, pad0, pad1;
+    uint32_t prim_id, moving;
+    float u_shift;
+    uint32_t pad;
 } rt_sphere;
 
 /* ConstantMedium (hittable.rs:820-891): boundary = refs[first .. first+count), a convex list */
@@ -203,10 +208,13 @@ int rt_film_download(rt_handle *h, float *rgb, float scale);
 int rt_get_stats(rt_handle *h, rt_stats *out);
 
 /* Parity hook: closest hit of the uploaded world for n host rays (o,d: n*3; time: n or NULL).
+ * origin_prim (n or NULL): id of the primitive each ray starts on, -1 for none -- what the
+ * shade pass records for every bounce ray, so that the surface a ray leaves is not met again
+ * at t ~ 0 (the reference relies on its 0.001 lower bound in f64 for that).
  * prim = user-visible primitive id or -1.  ConstantMedium draws are keyed by ray index. */
 int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d, const float *time,
-                       float tmin, float tmax, int32_t *hit, int32_t *prim, float *t, float *u,
-                       float *v);
+                       const int32_t *origin_prim, float tmin, float tmax, int32_t *hit, int32_t *prim,
+                       float *t, float *u, float *v);
 /* Camera rays exactly as the generate kernel makes them (camera.rs:409-430). */
 int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *params, uint32_t n,
                    const uint32_t *pixel, const uint32_t *stratum, float *o, float *d, float *time);

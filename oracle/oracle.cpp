@@ -1254,7 +1254,7 @@ int orc_camera_rays(orc_scene *s, const orc_camera *cb, const orc_render_params 
 
 int orc_intersect_batch(orc_scene *s, uint32_t n, const double *o, const double *d, const double *time,
                         double tmin, double tmax, int32_t *hit, int32_t *prim, double *t, double *u,
-                        double *v, double *second_t) {
+                        double *v, double *second_t, double *normal) {
     if (!s->world) return fail(s, "intersect_batch: no world set");
     Ctx c;
     c.rng.kind = ORC_RNG_PHILOX24;
@@ -1270,6 +1270,10 @@ int orc_intersect_batch(orc_scene *s, uint32_t n, const double *o, const double 
         t[k] = h ? h->t : INF;
         if (u) u[k] = h ? h->u : 0.0;
         if (v) v[k] = h ? h->v : 0.0;
+        if (normal) {
+            V3 nn = h ? h->normal : V3{0, 0, 0};
+            normal[3 * k] = nn.x, normal[3 * k + 1] = nn.y, normal[3 * k + 2] = nn.z;
+        }
         if (second_t) {
             second_t[k] = INF;
             if (h) {

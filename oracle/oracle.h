@@ -107,7 +107,7 @@ int orc_camera_rays(orc_scene *, const orc_camera *, const orc_render_params *, 
 /* closest hit of world for a batch. second_t: t of the runner-up primitive (inf if none). */
 int orc_intersect_batch(orc_scene *, uint32_t n, const double *o, const double *d, const double *time,
                         double tmin, double tmax, int32_t *hit, int32_t *prim, double *t, double *u,
-                        double *v, double *second_t);
+                        double *v, double *second_t, double *normal /* n*3 or NULL */);
 
 /* per-function hooks */
 void orc_sphere_uv(const double p[3], double uv[2]);            /* hittable.rs:150-162 */

@@ -84,19 +84,22 @@ def camera_rays(sb, cam: CameraSettings, pixel, stratum, seed=1, rng=RNG_PHILOX2
     return o
 
 
-def intersect_batch(sb, o, d, time=None, tmin=0.001, tmax=float("inf")):
+def intersect_batch(sb, o, d, time=None, tmin=0.001, tmax=float("inf"), want_normal=False):
     o = np.ascontiguousarray(o, np.float64).reshape(-1, 3)
     d = np.ascontiguousarray(d, np.float64).reshape(-1, 3)
     n = len(o)
     tm = np.ascontiguousarray(time, np.float64) if time is not None else None
     hit, prim = np.empty(n, np.int32), np.empty(n, np.int32)
     t, u, v, t2 = np.empty(n), np.empty(n), np.empty(n), np.empty(n)
+    nrm = np.empty((n, 3)) if want_normal else None
     ip = C.POINTER(C.c_int32)
     rc = lib.orc_intersect_batch(sb.handle, n, _dp(o), _dp(d), _dp(tm) if tm is not None else None, C.c_double(tmin),
                                  C.c_double(tmax), hit.ctypes.data_as(ip), prim.ctypes.data_as(ip), _dp(t), _dp(u),
-                                 _dp(v), _dp(t2))
+                                 _dp(v), _dp(t2), _dp(nrm) if want_normal else None)
     if rc < 0:
         raise RuntimeError(lib.orc_last_error(sb.handle).decode())
+    if want_normal:
+        return hit, prim, t, u, v, t2, nrm
     return hit, prim, t, u, v, t2
 
 

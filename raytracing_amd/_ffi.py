@@ -7,6 +7,11 @@ import ctypes as C
 import os
 from pathlib import Path
 
+# PyTorch ships its own HIP/HSA runtime (soname libamdhip64.so.7).  Two HIP runtimes in one
+# process leave the second without a device, so torch is loaded first and librt_amd.so then
+# binds to the runtime already in the process.
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+
 _LIB_PATH = Path(__file__).resolve().parent / "librt_amd.so"
 
 u32, u64, i32, f32, f64 = C.c_uint32, C.c_uint64, C.c_int32, C.c_float, C.c_double
@@ -25,7 +30,7 @@ class RtQuad(C.Structure):
 
 class RtSphere(C.Structure):
     _fields_ = [("c0", f32 * 3), ("radius", f32), ("cv", f32 * 3), ("mat", u32),
-                ("prim_id", u32), ("moving", u32), ("pad0", u32), ("pad1", u32)]
+                ("prim_id", u32), ("moving", u32), ("u_shift", f32), ("pad", u32)]
 
 
 class RtMedium(C.Structure):
@@ -97,7 +102,7 @@ SIGNATURES = {
     "rt_film_device_ptr": (C.c_int, [_vp, P(_vp), P(u64)]),
     "rt_film_download": (C.c_int, [_vp, P(f32), f32]),
     "rt_get_stats": (C.c_int, [_vp, P(RtStats)]),
-    "rt_intersect_batch": (C.c_int, [_vp, u32, P(f32), P(f32), P(f32), f32, f32, P(i32), P(i32), P(f32), P(f32), P(f32)]),
+    "rt_intersect_batch": (C.c_int, [_vp, u32, P(f32), P(f32), P(f32), P(i32), f32, f32, P(i32), P(i32), P(f32), P(f32), P(f32)]),
     "rt_camera_rays": (C.c_int, [_vp, P(RtCamera), P(RtRenderParams), u32, P(u32), P(u32), P(f32), P(f32), P(f32)]),
     "rt_eval_texture": (C.c_int, [_vp, u32, u32, P(f32), P(f32)]),
     "rt_philox": (C.c_int, [_vp, u32, P(u32), P(u32), P(u32)]),

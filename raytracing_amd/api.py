@@ -320,7 +320,7 @@ class Device:
     def synchronize(self):
         self._check(self.lib.rt_synchronize(self.h), "rt_synchronize")
 
-    def intersect_batch(self, o, d, time=None, tmin=0.001, tmax=float("inf")):
+    def intersect_batch(self, o, d, time=None, tmin=0.001, tmax=float("inf"), origin_prim=None):
         o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
         n = o.shape[0]
@@ -335,7 +335,11 @@ class Device:
         u = np.empty(n, np.float32)
         v = np.empty(n, np.float32)
         ip = C.POINTER(C.c_int32)
-        self._check(self.lib.rt_intersect_batch(self.h, n, o.ctypes.data_as(fp), d.ctypes.data_as(fp), tm,
+        frm = None
+        if origin_prim is not None:
+            origin_prim = np.ascontiguousarray(origin_prim, dtype=np.int32)
+            frm = origin_prim.ctypes.data_as(ip)
+        self._check(self.lib.rt_intersect_batch(self.h, n, o.ctypes.data_as(fp), d.ctypes.data_as(fp), tm, frm,
                                                 C.c_float(tmin), C.c_float(tmax), hit.ctypes.data_as(ip),
                                                 prim.ctypes.data_as(ip), t.ctypes.data_as(fp), u.ctypes.data_as(fp),
                                                 v.ctypes.data_as(fp)), "rt_intersect_batch")

@@ -35,6 +35,7 @@ struct rt_handle {
     uint32_t flat_first = 0, flat_count = 0, has_media = 0, n_prims = 0;
     bool has_specular = false;
     uint32_t n_textures = 0;
+    std::vector<uint32_t> prim_to_ref; // user-visible primitive id -> ref (parity hook)
 
     // queue
     Queue q{};
@@ -419,6 +420,13 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     h->has_specular = false;
     for (uint32_t i = 0; i < s->n_materials; ++i)
         if (s->materials[i].type == RT_MAT_METAL || s->materials[i].type == RT_MAT_DIELECTRIC) h->has_specular = true;
+    h->prim_to_ref.assign(s->n_prims, RT_REF_NONE);
+    auto note = [&](uint32_t id, uint32_t ref) {
+        if (id < s->n_prims) h->prim_to_ref[id] = ref;
+    };
+    for (uint32_t i = 0; i < s->n_quads; ++i) note(s->quads[i].prim_id, (RT_KIND_QUAD << RT_REF_KIND_SHIFT) | i);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) note(s->spheres[i].prim_id, (RT_KIND_SPHERE << RT_REF_KIND_SHIFT) | i);
+    for (uint32_t i = 0; i < s->n_media; ++i) note(s->media[i].prim_id, (RT_KIND_MEDIUM << RT_REF_KIND_SHIFT) | i);
     // A world that is one list of primitives takes the stack-free kernel.
     h->flat = false;
     h->flat_first = h->flat_count = 0;
@@ -609,8 +617,9 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     return 0;
 }
 
-int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d, const float *time, float tmin,
-                       float tmax, int32_t *hit, int32_t *prim, float *t, float *u, float *v) {
+int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d, const float *time,
+                       const int32_t *origin_prim, float tmin, float tmax, int32_t *hit, int32_t *prim, float *t, float *u,
+                       float *v) {
     if (!h) return -1;
     RT_HIP(hipSetDevice(h->device));
     if (!h->have_scene) return fail(h, "rt_intersect_batch: no scene uploaded");
@@ -618,7 +627,19 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (!o || !d || !hit || !prim || !t || !u || !v) return fail(h, "rt_intersect_batch: null array");
     float *d_o = nullptr, *d_d = nullptr, *d_time = nullptr, *d_f = nullptr;
     int *d_i = nullptr;
+    uint32_t *d_from = nullptr;
+    std::vector<uint32_t> from;
+    if (origin_prim) {
+        from.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            int32_t id = origin_prim[i];
+            if (id >= int32_t(h->prim_to_ref.size())) return fail(h, "rt_intersect_batch: origin_prim out of range");
+            from[i] = id < 0 ? RT_REF_NONE : h->prim_to_ref[id];
+        }
+    }
     hipError_t e = hipMalloc((void **)&d_o, size_t(n) * 3 * sizeof(float));
+    if (e == hipSuccess && origin_prim) e = hipMalloc((void **)&d_from, size_t(n) * sizeof(uint32_t));
+    if (e == hipSuccess && origin_prim) e = hipMemcpyAsync(d_from, from.data(), size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&d_d, size_t(n) * 3 * sizeof(float));
     if (e == hipSuccess && time) e = hipMalloc((void **)&d_time, size_t(n) * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&d_f, size_t(n) * 3 * sizeof(float));
@@ -629,10 +650,10 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (e == hipSuccess) {
         dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
         if (h->flat)
-            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, tmin, tmax, h->flat_first,
+            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, h->flat_first,
                                                                    h->flat_count, d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         else
-            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, tmin, tmax, 0u, 0u, d_i,
+            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, 0u, 0u, d_i,
                                                                     d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         e = hipGetLastError();
     }
@@ -642,7 +663,7 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (e == hipSuccess) e = hipMemcpyAsync(u, d_f + n, size_t(n) * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(v, d_f + 2 * size_t(n), size_t(n) * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    for (void *p : {(void *)d_o, (void *)d_d, (void *)d_time, (void *)d_f, (void *)d_i})
+    for (void *p : {(void *)d_o, (void *)d_d, (void *)d_time, (void *)d_f, (void *)d_i, (void *)d_from})
         if (p) (void)hipFree(p);
     if (e != hipSuccess) return fail(h, std::string("rt_intersect_batch: ") + hipGetErrorString(e));
     return 0;

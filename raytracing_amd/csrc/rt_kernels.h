@@ -110,39 +110,79 @@ __device__ __forceinline__ bool hit_quad(const float4 *__restrict__ Q, V3 o, V3 
 // discriminant of large spheres: disc/a = r^2 - |oc - (h/a) d|^2.
 // from_self: the ray starts on this sphere, so one root is 0 by construction and the other
 // is 2h/a; the reference reaches the same root after rejecting |t| < 0.001.
+// The quadratic a t^2 - 2 h t + c = 0 (h = d.oc, c = |oc|^2 - r^2) loses its small terms in
+// fp32 twice: oc = centre - o rounds away the low bits of o when the centre is far (a ground
+// sphere of radius 1000), and |oc|^2 - r^2 cancels when the origin is near the surface.  Both
+// are repaired with error-free transformations (TwoSum, FMA products); the discriminant comes
+// from whichever form is well conditioned: h^2 - a c near the surface, a (r^2 - |oc - (h/a) d|^2)
+// far from a small sphere.  Roots are then q/a and c/q with q = h + sign(h) sqrt(disc).
+__device__ __forceinline__ void two_sum(float a, float b, float &s, float &e) {
+#pragma clang fp contract(off)
+    s = a + b;
+    float bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
 __device__ __forceinline__ bool hit_sphere(const float4 *__restrict__ S, V3 o, V3 d, float time, float tlo,
                                            float thi, bool from_self, float &t) {
+#pragma clang fp contract(off) // the error terms below must see the same roundings as the sums
     float4 s0 = S[0], s1 = S[1];
     V3 center = fma3(mk(s1), time, mk(s0));
-    V3 oc = center - o;
-    float a = len2(d);
-    float h = dot(d, oc);
-    float inv_a = 1.0f / a;
-    float tc = h * inv_a;
-    V3 perp = fma3(d, -tc, oc);
-    float disc_a = fmaf(s0.w, s0.w, -len2(perp));
-    if (disc_a < 0.0f) return false;
+    V3 oc, ol; // oc + ol = centre - o exactly
+    two_sum(center.x, -o.x, oc.x, ol.x);
+    two_sum(center.y, -o.y, oc.y, ol.y);
+    two_sum(center.z, -o.z, oc.z, ol.z);
+    const float r = s0.w;
+    const float a = len2(d);
+    const float h = dot(d, oc) + dot(d, ol);
+    const float inv_a = 1.0f / a;
     float root;
     if (from_self) {
-        root = 2.0f * tc;
+        root = 2.0f * h * inv_a;
         if (!(tlo < root && root < thi)) return false;
+        // the reference still needs a real discriminant here
+        V3 perp0 = fma3(d, -(h * inv_a), oc);
+        if (fmaf(r, r, -len2(perp0)) < 0.0f) return false;
+        t = root;
+        return true;
+    }
+    // c = |oc|^2 - r^2, compensated
+    float px = oc.x * oc.x, py = oc.y * oc.y, pz = oc.z * oc.z, pr = r * r;
+    float low = fmaf(oc.x, oc.x, -px) + fmaf(oc.y, oc.y, -py) + fmaf(oc.z, oc.z, -pz) - fmaf(r, r, -pr);
+    low = fmaf(2.0f, dot(oc, ol), low);
+    float s1_, e1, s2_, e2, s3_, e3;
+    two_sum(px, py, s1_, e1);
+    two_sum(s1_, pz, s2_, e2);
+    two_sum(s2_, -pr, s3_, e3);
+    const float c = s3_ + (e1 + e2 + e3 + low);
+    float disc;
+    if (fabsf(c) < pr) {
+        disc = fmaf(h, h, -(a * c));
     } else {
-        float dt = sqrtf(disc_a * inv_a);
-        root = tc - dt;
-        if (!(tlo < root && root < thi)) {
-            root = tc + dt;
-            if (!(tlo < root && root < thi)) return false;
-        }
+        V3 perp = fma3(d, -(h * inv_a), oc) + ol;
+        disc = a * fmaf(r, r, -len2(perp));
+    }
+    if (disc < 0.0f) return false;
+    const float q = h + copysignf(sqrtf(disc), h);
+    const float ta = c / q, tb = q * inv_a;
+    const float t_near = fminf(ta, tb), t_far = fmaxf(ta, tb);
+    root = t_near;
+    if (!(tlo < root && root < thi)) {
+        root = t_far;
+        if (!(tlo < root && root < thi)) return false;
     }
     t = root;
     return true;
 }
 
-// hittable.rs:150-162
-__device__ __forceinline__ void sphere_uv(V3 n, float &u, float &v) {
+// hittable.rs:150-162; u_shift undoes a baked RotateY (longitude is taken in the sphere's frame)
+__device__ __forceinline__ void sphere_uv(V3 n, float u_shift, float &u, float &v) {
     float theta = acosf(fminf(fmaxf(-n.y, -1.0f), 1.0f));
     float phi = atan2f(-n.z, n.x) + RT_PI;
     u = phi * (0.5f * RT_INV_PI);
+    if (u_shift != 0.0f) {
+        u += u_shift;
+        u -= floorf(u);
+    }
     v = theta * RT_INV_PI;
 }
 
@@ -607,7 +647,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
     const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
     V3 n;
     uint32_t mat_id;
-    float u = h.z, v = h.w;
+    float u = h.z, v = h.w, u_shift = 0.f;
     bool front = true;
     if (kind == RT_KIND_QUAD) {
         const float4 *Q = sc.quads + 6 * idx;
@@ -619,6 +659,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
         V3 center = fma3(mk(s1), time, mk(s0));
         n = (p - center) * (1.0f / s0.w);
         mat_id = fbits(s1.w);
+        u_shift = S[2].z;
     } else { // ConstantMedium: arbitrary normal, front face (hittable.rs:877-885)
         n = {1.f, 0.f, 0.f};
         mat_id = sc.media[idx].mat;
@@ -628,7 +669,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
         if (!front) n = -n;
     }
     const rt_material m = sc.mats[mat_id];
-    if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u, v);
+    if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
 
     if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
         if (front) film_add(film, pixel, thr * tex_value(sc, m.tex, u, v, p));
@@ -766,7 +807,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, DScene sc, DCamera cam
 // ------------------------------------------------------------------ hooks
 template <bool FLAT>
 __global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n, const float *o3, const float *d3,
-                                                            const float *time, float tmin, float tmax,
+                                                            const float *time, const uint32_t *origin_ref, float tmin, float tmax,
                                                             uint32_t flat_first, uint32_t flat_count, int *hit,
                                                             int *prim, float *t, float *u, float *v) {
     __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
@@ -775,11 +816,12 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n
     V3 o = {o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d = {d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
     float tm = time ? time[i] : 0.f;
     RayCtx rc{0u, 0u, i, 0u, 0u};
+    const uint32_t from = origin_ref ? origin_ref[i] : RT_REF_NONE;
     Best best;
     if (FLAT)
-        scan_flat(sc, flat_first, flat_count, o, d, tm, tmin, tmax, RT_REF_NONE, rc, best);
+        scan_flat(sc, flat_first, flat_count, o, d, tm, tmin, tmax, from, rc, best);
     else
-        traverse<false>(sc, o, d, tm, tmin, tmax, RT_REF_NONE, rc, s_stack + threadIdx.x, nullptr, best);
+        traverse<false>(sc, o, d, tm, tmin, tmax, from, rc, s_stack + threadIdx.x, nullptr, best);
     int pid = -1;
     float uu = best.u, vv = best.v;
     if (best.ref != RT_REF_NONE) {
@@ -792,7 +834,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n
             pid = int(fbits(s2.x));
             V3 center = fma3(mk(s1), tm, mk(s0));
             V3 nn = (fma3(d, best.t, o) - center) * (1.0f / s0.w);
-            sphere_uv(nn, uu, vv);
+            sphere_uv(nn, s2.z, uu, vv);
         } else {
             pid = int(sc.media[idx].prim_id);
             uu = vv = __builtin_nanf("");

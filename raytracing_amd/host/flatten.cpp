@@ -208,6 +208,8 @@ struct Flattener {
         r.mat = material(s.material.get());
         r.prim_id = uint32_t(prim_id_of(s));
         r.moving = (cv.x != 0.0 || cv.y != 0.0 || cv.z != 0.0) ? 1u : 0u;
+        // net rotation about y of the baked map: m[0][0] = cos, m[0][2] = sin
+        r.u_shift = float(-std::atan2(xf.m[0][2], xf.m[0][0]) / (2.0 * 3.14159265358979323846));
         fs.spheres.push_back(r);
         // a little slack for the fp32 copies of centre and radius
         double rad = s.radius * (1.0 + 1e-6) + 1e-6 * (std::fabs(c0.x) + std::fabs(c0.y) + std::fabs(c0.z));
@@ -405,23 +407,22 @@ struct Flattener {
     }
 
     uint32_t light_prim(const Hittable &h) {
-        auto it = identity_refs.find(&h);
-        if (it != identity_refs.end()) return it->second;
-        Box b;
-        Xf id;
         if (h.kind() == Hittable::QUAD) {
-            auto &q = static_cast<const Parallelogram &>(h);
-            if (q.shape != RT_SHAPE_PARALLELOGRAM)
+            if (static_cast<const Parallelogram &>(h).shape != RT_SHAPE_PARALLELOGRAM)
                 throw Error("flatten: only Parallelogram implements pdf_value/random (hittable.rs:377-395)");
-            return quad(q, id, b);
-        }
-        if (h.kind() == Hittable::SPHERE) {
+        } else if (h.kind() == Hittable::SPHERE) {
             auto &s = static_cast<const Sphere &>(h);
             if (s.center_vec.x != 0 || s.center_vec.y != 0 || s.center_vec.z != 0)
                 throw Error("flatten: a moving sphere cannot be a light");
-            return sphere(s, id, b);
+        } else {
+            throw Error("flatten: lights must be a Parallelogram, a Sphere or a HittableVec of those");
         }
-        throw Error("flatten: lights must be a Parallelogram, a Sphere or a HittableVec of those");
+        auto it = identity_refs.find(&h);
+        if (it != identity_refs.end()) return it->second; // the world's own primitive, not a copy
+        Box b;
+        Xf id;
+        if (h.kind() == Hittable::QUAD) return quad(static_cast<const Parallelogram &>(h), id, b);
+        return sphere(static_cast<const Sphere &>(h), id, b);
     }
 };
 

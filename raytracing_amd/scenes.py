@@ -175,12 +175,12 @@ def book2_final(sb: SceneBuilder, width=800, spp=10000, boxes_per_side=20, cloud
     return cam
 
 
-def stress(sb: SceneBuilder, n_prims=1_000_000, width=3840, height=2160, spp=4096):
+def stress(sb: SceneBuilder, n_prims=1_000_000, width=3840, height=2160, spp=4096, extent=100.0):
     rng = np.random.Generator(np.random.Philox(key=0x57E55))
     mats = [sb.lambertian(tuple(rng.random(3))) for _ in range(32)]
     metals = [sb.metal(tuple(0.5 + 0.5 * rng.random(3)), 0.3 * rng.random()) for _ in range(8)]
     glass = sb.dielectric(1.5)
-    centers = rng.random((n_prims, 3)) * 200.0 - 100.0
+    centers = (rng.random((n_prims, 3)) * 2.0 - 1.0) * extent
     kind = rng.random(n_prims)
     mat_pick = rng.random(n_prims)
     size = rng.random(n_prims)
@@ -204,5 +204,5 @@ def stress(sb: SceneBuilder, n_prims=1_000_000, width=3840, height=2160, spp=409
     cam.image_width, cam.image_height = width, height
     cam.samples_per_px, cam.max_depth = spp, 50
     cam.vfov = 40.0
-    cam.camera_center, cam.camera_target = (0.0, 30.0, 260.0), (0.0, 0.0, 0.0)
+    cam.camera_center, cam.camera_target = (0.0, 0.3 * extent, 2.6 * extent), (0.0, 0.0, 0.0)
     return cam

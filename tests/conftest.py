@@ -1,0 +1,23 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def device():
+    import raytracing_amd as ra
+    if ra.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests must run on the GPU box")
+    dev = ra.Device(0)
+    yield dev
+    dev.close()

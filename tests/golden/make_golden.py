@@ -1,0 +1,41 @@
+"""Regenerates the fixtures in this directory.  Run from the repository root:
+    python tests/golden/make_golden.py
+* new_cornell_blockmeans.npy comes from the reference's own output image
+  assets/new-cornell.png (600x600 linear PNG written by its PngWriter): 20x20 block means of
+  the 8-bit values / 255.  Needs /root/reference; skipped when it is absent.
+* the rest are outputs of the CPU oracle (oracle/liboracle.so) on fixed seeds.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+HERE = Path(__file__).resolve().parent
+
+import raytracing_amd as ra  # noqa: E402
+from oracle import oracle_py as orc  # noqa: E402
+import helpers  # noqa: E402
+
+
+def main():
+    ref_png = Path("/root/reference/assets/new-cornell.png")
+    if ref_png.exists():
+        from PIL import Image
+        a = np.asarray(Image.open(ref_png)).astype(np.float64) / 255.0
+        bm = a.reshape(20, 30, 20, 30, 3).mean(axis=(1, 3)).astype(np.float32)
+        np.save(HERE / "new_cornell_blockmeans.npy", bm)
+    for name, fn, mode in (("c1", ra.scenes.cornell_main, orc.MODE_REF_EXACT), ("c3", ra.scenes.cornell_book3, orc.MODE_BOOK3)):
+        host, osb, cam = helpers.build_both(fn, width=64, spp=16)
+        film, _, cnt = orc.render(osb, cam, mode=mode, seed=1)
+        np.save(HERE / f"{name}_oracle_64x64_spp16.npy", (film / cam.effective_spp).astype(np.float32))
+        o, d, tm, frm = helpers.ray_batch(osb, cam, 4096, seed=7, bbox=((0, 0, 0), (555, 555, 555)))
+        hit, prim, t, u, v, t2 = orc.intersect_batch(osb, o, d, tm)
+        np.savez_compressed(HERE / f"{name}_rays.npz", o=o, d=d, time=tm, origin_prim=frm, hit=hit, prim=prim, t=t, u=u, v=v, second_t=t2,
+                            segments=np.array([cnt["segments"]]))
+
+
+if __name__ == "__main__":
+    main()

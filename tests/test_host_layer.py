@@ -1,0 +1,474 @@
+"""Host scene layer of the product (no GPU needed): C ABI surface, CameraBuilder, TOML loader,
+BVH build, flattening, image writers.  The oracle appears only as the checker."""
+import ctypes as C
+import math
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import _ffi
+from oracle import config_oracle
+from oracle import oracle_py as orc
+import helpers
+
+ROOT = Path(__file__).resolve().parent.parent
+lib = _ffi.lib
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "rt_amd.h").read_text()
+    declared = set(re.findall(r"^(?:int|void|double|const char \*|rth_scene \*)\s*\*?(rth?_[a-z0-9_]+)\s*\(", header, re.M))
+    assert len(declared) > 55
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in rt_amd.h but not exported"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+
+
+def test_no_gpu_means_loud_failure():
+    if ra.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(ra.RtError, match="no HIP device|hip"):
+        ra.Device(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    for p in list((ROOT / "raytracing_amd").rglob("*")) + list((ROOT / "include").rglob("*")):
+        if p.suffix in (".py", ".h", ".hpp", ".cpp", ".hip"):
+            text = p.read_text()
+            assert "liboracle" not in text and "oracle_py" not in text and "orc_" not in text, p
+
+
+# ---------------------------------------------------------------- reference KATs on the host side
+def test_host_sphere_uv_interval_color_kats():
+    for p, uv in [((1, 0, 0), (0.5, 0.5)), ((-1, 0, 0), (0.0, 0.5)), ((0, 1, 0), (0.5, 1.0)),
+                  ((0, -1, 0), (0.5, 0.0)), ((0, 0, 1), (0.25, 0.5)), ((0, 0, -1), (0.75, 0.5))]:
+        out = (C.c_double * 2)()
+        lib.rth_sphere_uv((C.c_double * 3)(*map(float, p)), out)
+        assert (out[0], out[1]) == uv
+    out = (C.c_double * 2)()
+    assert lib.rth_interval_overlap(10.0, 20.0, 15.0, 25.0, out) == 1 and out[:] == [15.0, 20.0]
+    assert lib.rth_interval_overlap(20.0, 25.0, 10.0, 20.0, out) == 0
+    assert lib.rth_interval_surrounds(5.0, 10.0, 5.0) == 0 and lib.rth_interval_contains(5.0, 10.0, 5.0) == 1
+    assert lib.rth_interval_clamp(5.0, 10.0, 20.0) == 10.0
+    lib.rth_interval_expand(5.0, 10.0, 1.0, out)
+    assert out[:] == [4.5, 10.5]
+    rgb = (C.c_double * 3)()
+    for hexv in (0xfff, 0x0ff, 0xA60D0D, 0x1000, 0xBABABA, 0x123):
+        want = (C.c_double * 3)()
+        lib.rth_color_hex(hexv, rgb)
+        orc.lib.orc_color_hex(hexv, want)
+        assert rgb[:] == want[:]
+    q, q2 = (C.c_uint8 * 3)(), (C.c_uint8 * 3)()
+    for v in [(0.999, 0.5, 1.0), (float("nan"), float("inf"), -1.0), (0.25, 0.0, 2.0)]:
+        for gamma in (0, 1):
+            lib.rth_color_quantize((C.c_double * 3)(*v), gamma, q)
+            orc.lib.orc_color_quantize((C.c_double * 3)(*v), gamma, q2)
+            assert q[:] == q2[:]
+
+
+# ---------------------------------------------------------------- camera
+def test_camera_defaults_match_reference():
+    b = _ffi.CameraBuilderStruct()
+    lib.rth_camera_defaults(C.byref(b))
+    assert (b.image_width, b.image_height, b.samples_per_px, b.max_depth) == (400, 200, 10, 10)
+    assert b.vfov_deg == 90.0 and b.focal_length == 1.0 and b.background_sky == 1
+    assert list(b.target) == [0.0, 0.0, -1.0] and list(b.vup) == [0.0, 1.0, 0.0]
+    assert ra.CameraSettings() == ra.CameraSettings(400, 200, 90.0, 10, 10)
+
+
+def test_with_aspect_ratio_rounds_height():
+    b = _ffi.CameraBuilderStruct()
+    lib.rth_camera_defaults(C.byref(b))
+    assert lib.rth_camera_with_aspect_ratio(C.byref(b), 1200, 16.0 / 9.0) == 0
+    assert (b.image_width, b.image_height) == (1200, 675)
+    assert lib.rth_camera_with_aspect_ratio(C.byref(b), 600, 1000.0) < 0  # outside 0.1..=100 (camera.rs:83-86)
+
+
+def test_camera_build_main_rs_values():
+    sb = ra.SceneBuilder()
+    cam = ra.scenes.cornell_main(sb)
+    c = cam.build()
+    assert (c.image_width, c.image_height, c.sqrt_spp, c.max_depth) == (600, 600, 4, 50)  # 20 spp -> 16
+    # looking down +z from z=-800: w = (0,0,-1), u = vup x w = (-1,0,0), v = (0,1,0)
+    vh = 2.0 * math.tan(math.radians(40.0) / 2.0)
+    assert np.allclose(list(c.pxdelta_u), [-vh / 600, 0, 0], atol=1e-15)
+    assert np.allclose(list(c.pxdelta_v), [0, -vh / 600, 0], atol=1e-15)
+    assert np.allclose(list(c.pixel_00), [278 + vh / 2 - vh / 1200, 278 + vh / 2 - vh / 1200, -799.0], atol=1e-12)
+    assert c.background_sky == 0 and list(c.background) == [0, 0, 0]
+
+
+def test_camera_vup_cross_is_not_renormalised():
+    """u = vup x w is only labelled unit (vec.rs:299-306), so a tilted view shrinks the viewport."""
+    cam = ra.CameraSettings(image_width=100, image_height=100, vfov=20.0)
+    cam.camera_center, cam.camera_target = (13.0, 2.0, 3.0), (0.0, 0.0, 0.0)
+    c = cam.build()
+    w = np.array([13.0, 2.0, 3.0]) / math.sqrt(13 ** 2 + 2 ** 2 + 3 ** 2)
+    sin_angle = np.linalg.norm(np.cross([0, 1.0, 0], w))
+    vh = 2.0 * math.tan(math.radians(10.0))
+    assert np.linalg.norm(list(c.pxdelta_u)) == pytest.approx(vh * sin_angle / 100, rel=1e-12)
+    assert sin_angle < 0.99
+
+
+def test_camera_builder_validation_messages():
+    cam = ra.CameraSettings(image_width=1, image_height=0, vfov=400.0, samples_per_px=0, max_depth=0,
+                            defocus_angle=200.0, focal_length=-1.0, background=(2.0, 0, 0))
+    with pytest.raises(ra.RtError) as e:
+        cam.build()
+    msg = str(e.value)
+    for part in ("CameraBuilder::dimensions: Invalid width", "CameraBuilder::dimensions: Invalid height",
+                 "CameraBuilder::max_depth", "CameraBuilder::antialias", "CameraBuilder::focal_length",
+                 "CameraBuilder::vfov", "CameraBuilder::defocus_angle", "CameraBuilder::background"):
+        assert part in msg, part
+
+
+def test_spp_rounds_down_to_a_square():
+    for asked, got in ((20, 16), (500, 484), (1000, 961), (10000, 10000), (4096, 4096), (1, 1), (3, 1)):
+        cam = ra.CameraSettings(samples_per_px=asked)
+        assert cam.build().sqrt_spp ** 2 == got == cam.effective_spp
+
+
+# ---------------------------------------------------------------- flatten
+def _desc_arrays(d):
+    quads = [d.quads[i] for i in range(d.n_quads)]
+    refs = [d.refs[i] for i in range(d.n_refs)]
+    nodes = [d.nodes[i] for i in range(d.n_nodes)]
+    return quads, refs, nodes
+
+
+def test_flatten_cornell_is_one_flat_list_in_reference_order():
+    sb = ra.SceneBuilder()
+    ra.scenes.cornell_main(sb)
+    d = sb.flatten().contents
+    quads, refs, nodes = _desc_arrays(d)
+    assert (d.n_nodes, d.n_refs, d.n_quads, d.n_spheres, d.n_lights, d.lights_kind, d.n_prims) == (1, 18, 18, 0, 1, 1, 18)
+    assert nodes[0].right == _ffi.RT_NODE_LEAF and nodes[0].count == 18 and d.max_stack == 0
+    # visiting order of HittableVec::hit: 5 walls, light, tall box (6), cube (6); ids = creation order
+    assert [quads[r & 0x1FFFFFFF].prim_id for r in refs] == list(range(18))
+    assert all((r >> 29) == _ffi.RT_KIND_QUAD for r in refs)
+    assert d.light_refs[0] == refs[5]  # the light is the world's own quad, not a copy
+    light = quads[5]
+    assert list(light.q) == [343.0, 554.0, 332.0] and np.allclose(list(light.n), [0, -1, 0]) and light.area == 13650.0
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    texs = [d.textures[i] for i in range(d.n_textures)]
+    assert mats[light.mat].type == 1 and list(texs[mats[light.mat].tex].color) == [20.0, 20.0, 20.0]
+    green = texs[mats[quads[0].mat].tex]
+    assert np.allclose(list(green.color), [0x1F / 255, 0x73 / 255, 0x26 / 255])
+
+
+def test_flatten_bakes_rotate_translate_like_the_reference_maps_points():
+    sb = ra.SceneBuilder()
+    ra.scenes.cornell_main(sb)
+    d = sb.flatten().contents
+    q = d.quads[6]  # front face of the tall box: corner (0,0,165), u=(165,0,0), v=(0,330,0)
+    th = math.radians(15.0)
+    c, s = math.cos(th), math.sin(th)
+
+    def to_world(p):  # hittable.rs:795-799 then Translate
+        return np.array([c * p[0] + s * p[2] + 265.0, p[1], -s * p[0] + c * p[2] + 295.0])
+
+    assert np.allclose(list(q.q), to_world((0, 0, 165.0)), atol=1e-4)
+    assert np.allclose(list(q.u), to_world((165.0, 0, 165.0)) - to_world((0, 0, 165.0)), atol=1e-4)
+    n = np.cross(list(q.u), list(q.v))
+    assert np.allclose(list(q.n), n / np.linalg.norm(n), atol=1e-6)
+    assert q.d == pytest.approx(np.dot(list(q.n), list(q.q)), rel=1e-5)
+    # alpha/beta vectors reproduce w.((p-Q) x v), w.(u x (p-Q))
+    p = np.array(list(q.q)) + 0.3 * np.array(list(q.u)) + 0.6 * np.array(list(q.v))
+    ph = p - np.array(list(q.q))
+    assert np.dot(ph, list(q.avec)) == pytest.approx(0.3, abs=1e-5)
+    assert np.dot(ph, list(q.bvec)) == pytest.approx(0.6, abs=1e-5)
+
+
+def _check_bvh_invariants(d):
+    quads, refs, nodes = _desc_arrays(d)
+    spheres = [d.spheres[i] for i in range(d.n_spheres)]
+
+    def prim_box(ref):
+        kind, idx = ref >> 29, ref & 0x1FFFFFFF
+        if kind == _ffi.RT_KIND_QUAD:
+            q = quads[idx]
+            pts = np.array([np.array(list(q.q)) + a * np.array(list(q.u)) + b * np.array(list(q.v)) for a in (0, 1) for b in (0, 1)])
+            return pts.min(0), pts.max(0)
+        if kind == _ffi.RT_KIND_SPHERE:
+            s = spheres[idx]
+            c0, c1 = np.array(list(s.c0)), np.array(list(s.c0)) + np.array(list(s.cv))
+            return np.minimum(c0, c1) - s.radius, np.maximum(c0, c1) + s.radius
+        m = d.media[idx]
+        boxes = [prim_box(refs[m.first + k]) for k in range(m.count)]
+        return np.min([b[0] for b in boxes], 0), np.max([b[1] for b in boxes], 0)
+
+    def box_of(ref, parent_index):
+        if (ref >> 29) != _ffi.RT_KIND_NODE:
+            return prim_box(ref)
+        i = ref & 0x1FFFFFFF
+        assert i > parent_index, "children must point forward"
+        n = nodes[i]
+        if n.right == _ffi.RT_NODE_LEAF:
+            boxes = [box_of(refs[n.left + k], i) for k in range(n.count)]
+        else:
+            lb, rb = box_of(n.left, i), box_of(n.right, i)
+            tol = 1e-3
+            assert (np.array(list(n.lmin)) <= lb[0] + tol).all() and (np.array(list(n.lmax)) >= lb[1] - tol).all()
+            assert (np.array(list(n.rmin)) <= rb[0] + tol).all() and (np.array(list(n.rmax)) >= rb[1] - tol).all()
+            boxes = [lb, rb]
+        return np.min([b[0] for b in boxes], 0), np.max([b[1] for b in boxes], 0)
+
+    box_of(d.root, -1)
+
+
+def test_flatten_bvh_scenes_keep_boxes_conservative():
+    sb = ra.SceneBuilder()
+    ra.scenes.book1_final(sb, width=64, spp=4, grid=4)
+    d = sb.flatten().contents
+    assert d.n_spheres == sb.prim_count() and d.n_nodes > 10 and 0 < d.max_stack <= 32
+    _check_bvh_invariants(d)
+    sb2 = ra.SceneBuilder()
+    ra.scenes.book2_final(sb2, width=64, spp=4, boxes_per_side=4, cloud=50, earth=np.zeros((4, 8, 3), np.uint8))
+    d2 = sb2.flatten().contents
+    assert d2.n_media == 2 and d2.n_quads == 16 * 6 + 1 and d2.n_noise == 1 and d2.n_texel_bytes == 4 * 8 * 3
+    assert d2.n_prims == sb2.prim_count()
+    _check_bvh_invariants(d2)
+    needs_uv = [d2.materials[i].needs_uv for i in range(d2.n_materials)]
+    assert sum(needs_uv) == 1  # only the image-textured Lambertian
+
+
+def test_bvh_build_follows_reference_algorithm():
+    """Median split on the longest axis: 2N-1 nodes for a power-of-two leaf count, depth log2(N)+...,
+    and the same statistics as the oracle's independent build."""
+    rng = np.random.default_rng(2)
+    centers = rng.random((64, 3)) * np.array([100.0, 10.0, 10.0])
+    stats = []
+    for sb in (ra.SceneBuilder(), orc.scene()):
+        m = sb.lambertian((0.5, 0.5, 0.5))
+        objs = [sb.sphere(tuple(c), 0.5, m) for c in centers]
+        stats.append(sb.bvh_stats(sb.bvh(objs)))
+    assert stats[0] == stats[1] == (63, 6)  # interior nodes only: leaves are the objects themselves
+    sb = ra.SceneBuilder()
+    with pytest.raises(ra.RtError, match="empty"):
+        sb.bvh([])  # the reference recurses forever on an empty list (boundingbox.rs:189-203)
+
+
+def test_lights_rules():
+    sb = ra.SceneBuilder()
+    m = sb.lambertian((0.5, 0.5, 0.5))
+    tri = sb.quad((0, 0, 0), (1, 0, 0), (0, 1, 0), m, shape=ra.SHAPE_TRIANGLE)
+    sb.set_world(sb.list([tri]))
+    sb.set_lights(tri)
+    with pytest.raises(ra.RtError, match="Parallelogram"):
+        sb.flatten()  # only Parallelogram has pdf_value/random (hittable.rs:377-395)
+    sb.set_lights(sb.bvh([tri]))
+    with pytest.raises(ra.RtError, match="lights must be"):
+        sb.flatten()
+
+
+# ---------------------------------------------------------------- TOML loader vs the oracle-side reading
+SAMPLE = '''
+[textures.red]
+type = "SolidColor"
+color = "#ff0000"
+
+[textures.cx]
+type = "Checkerboard"
+textures = ["#ff0", 0xfff]
+scale = 1.0
+
+[materials.solid_red]
+# Shortcut for Lambertian material with SolidColor texture
+type = "SolidColor"
+color = 0xff0000
+
+[materials.light2]
+type = "ColoredLight"
+color = 0xfff
+# 10x white
+brightness = 10
+
+[materials.chk]
+type = "lambertian"
+texture = "cx"
+
+[materials.mirror]
+type = "Fuzzy"
+albedo = "#cccccc"
+fuzz = 25
+
+[materials.glass]
+type = "Dielectric"
+refractive_index = 1.5
+
+[[objects]]
+type = "Parallelogram"
+corner = [-3, -2, 5]
+vectors = [[0, 0, -4], [0, 4, 0]]
+material = "solid_red"
+
+[[objects]]
+type = "sphere"
+center = [0.5, 1, -2.25]
+radius = 2
+material = "glass"
+
+[[objects]]
+type = "Disc"
+center = [0, 0, 0]
+vectors = [[1, 0, 0], [0, 0, 1.5]]
+material = "chk"
+
+[[objects]]
+type = "Triangle"
+points = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+material = "mirror"
+
+[[objects]]
+type = "Parallelogram"
+corner = [0, 5, 0]
+vectors = [[1, 0, 0], [0, 0, 1]]
+material = "light2"
+'''
+
+
+def _flat_summary(sb):
+    d = sb.flatten().contents
+    mats = [d.materials[i] for i in range(d.n_materials)]
+    texs = [d.textures[i] for i in range(d.n_textures)]
+
+    def tex_desc(i):
+        t = texs[i]
+        if t.type == 0:
+            return ("solid", tuple(np.round(list(t.color), 6)))
+        if t.type == 1:
+            return ("checker", round(t.scale, 6), tex_desc(t.a), tex_desc(t.b))
+        return ("other", t.type)
+
+    def mat_desc(i):
+        m = mats[i]
+        if m.type in (0, 1, 4):
+            return (m.type, tex_desc(m.tex))
+        return (m.type, tuple(np.round(list(m.albedo), 6)), round(m.param, 6))
+
+    out = {}
+    for i in range(d.n_quads):
+        q = d.quads[i]
+        out[q.prim_id] = ("quad", q.shape, tuple(q.q), tuple(q.u), tuple(q.v), mat_desc(q.mat))
+    for i in range(d.n_spheres):
+        s = d.spheres[i]
+        out[s.prim_id] = ("sphere", tuple(s.c0), s.radius, mat_desc(s.mat))
+    return out
+
+
+@pytest.mark.parametrize("text", [SAMPLE, ra.scenes.cornell_toml_text()])
+def test_toml_loader_agrees_with_independent_reading(text):
+    a = ra.SceneBuilder()
+    a.set_world(a.load_toml(text))
+    b = ra.SceneBuilder()  # same host library, objects created through the oracle-side config reader
+    b.set_world(b.list(config_oracle.toml_objects(b, text)))
+    sa, sb_ = _flat_summary(a), _flat_summary(b)
+    assert sa == sb_ and len(sa) >= 5
+
+
+def test_toml_sample_details():
+    sb = ra.SceneBuilder()
+    sb.set_world(sb.load_toml(SAMPLE))
+    s = _flat_summary(sb)
+    assert s[0][5] == (0, ("solid", (1.0, 0.0, 0.0)))
+    assert s[2][1] == ra.SHAPE_DISC and s[2][2] == (-1.0, 0.0, -1.5) and s[2][3] == (2.0, 0.0, 0.0)  # from_center
+    # checker of "#ff0" (3 nibbles * 16 -> 240) and 0xfff, scale stored as 1/scale
+    assert s[2][5] == (0, ("checker", 1.0, ("solid", (0.941176, 0.941176, 0.0)), ("solid", (0.941176,) * 3)))
+    assert s[3][1] == ra.SHAPE_TRIANGLE and s[3][5] == (2, (0.8, 0.8, 0.8), 0.25)  # fuzz 25 -> 0.25
+    assert s[4][5] == (1, ("solid", (9.411765,) * 3))  # 240/255 * 10
+    assert sb.material_by_name("glass") >= 0
+    with pytest.raises(ra.RtError):
+        sb.material_by_name("nope")
+
+
+@pytest.mark.parametrize("text,needle", [
+    ("materials = {}\nobjects = []\n", "config.textures must be a table"),
+    ("textures = {}\nobjects = []\n", "config.materials must be a table"),
+    ("textures = {}\nmaterials = {}\n", "config.objects must be a list of tables"),
+    ("textures = {}\n[materials.a]\ntype = 'SolidColor'\n[[objects]]\ntype='Sphere'\n", "config.materials.a.color must be provided"),
+    ("textures = {}\n[materials.a]\ntype = 'Plaid'\ncolor=1\n[[objects]]\ntype='Sphere'\n", "must be a valid material type"),
+    ("textures = {}\n[materials.a]\ntype = 'SolidColor'\ncolor=1\n[[objects]]\ntype='Sphere'\ncenter=[0,0,0]\nradius=1\nmaterial='b'\n",
+     "does not describe a valid texture"),
+    ("textures = {}\n[materials.a]\ntype = 'SolidColor'\ncolor=1\n[[objects]]\ntype='Parallelogram'\ncorner=[0,0]\nvectors=[[1,0,0],[0,1,0]]\nmaterial='a'\n",
+     "must be a valid 3D point"),
+    ("textures = {}\n[materials.a]\ntype = 'SolidColor'\ncolor='#zz'\n[[objects]]\ntype='Sphere'\n", "Invalid hex string"),
+    ("textures = {}\n[materials.a]\ntype = 'Metal'\nalbedo=1\nfuzz=150\n[[objects]]\ntype='Sphere'\n", "Invalid fuzz value"),
+    ("textures = {}\n[materials.a\n", "TOML parse error"),
+    ("textures = {}\n[materials.a]\ntype = 'SolidColor'\ncolor=1\n[[objects]]\ntype='Blob'\n", "must be a valid object type"),
+])
+def test_toml_errors(text, needle):
+    sb = ra.SceneBuilder()
+    with pytest.raises(ra.RtError, match=re.escape(needle)):
+        sb.load_toml(text)
+    with pytest.raises((config_oracle.ConfigError, Exception)):
+        config_oracle.load(ra.SceneBuilder(), text)
+
+
+def test_toml_parser_value_forms():
+    text = '''
+textures = { }   # inline empty table
+[materials]
+a = { type = "SolidColor", color = 0x00_ff_00 }
+"b c".type = 'ColoredLight'
+"b c".color = "#102030"
+"b c".brightness = 2.5e0
+[[objects]]
+type = "Sphere"
+center = [
+  1, 2.0,   # comment inside an array
+  -3e0,
+]
+radius = +1
+material = "a"
+'''
+    sb = ra.SceneBuilder()
+    sb.set_world(sb.load_toml(text))
+    s = _flat_summary(sb)
+    assert s[0] == ("sphere", (1.0, 2.0, -3.0), 1.0, (0, ("solid", (0.0, 1.0, 0.0))))
+    assert sb.material_by_name("b c") >= 0
+
+
+# ---------------------------------------------------------------- image writers / reader
+def test_png_ppm_writers_and_reader(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.random((5, 7, 3)).astype(np.float32) * 1.2 - 0.1
+    img[0, 0] = [np.nan, np.inf, 0.999]
+    fp = C.POINTER(C.c_float)
+    png, ppm = tmp_path / "a.png", tmp_path / "a.ppm"
+    assert lib.rth_write_png(str(png).encode(), 7, 5, img.ctypes.data_as(fp)) == 0
+    assert lib.rth_write_ppm(str(ppm).encode(), 7, 5, img.ctypes.data_as(fp)) == 0
+    got = np.asarray(Image.open(png))
+    want = np.floor(np.clip(np.nan_to_num(img.astype(np.float64), nan=0.0, posinf=1.0), 0, 1) * 255).astype(np.uint8)
+    assert np.array_equal(got, want) and tuple(got[0, 0]) == (0, 255, 254)  # linear, truncated (export.rs:77-81)
+    toks = ppm.read_text().split()
+    assert toks[:4] == ["P3", "7", "5", "255"]
+    g = np.array(toks[4:], dtype=int).reshape(5, 7, 3)
+    lin = np.clip(np.nan_to_num(img.astype(np.float64), nan=0.0, posinf=np.inf), 0, None)
+    assert np.array_equal(g, np.floor(np.clip(np.sqrt(lin), 0, 1) * 255).astype(int))  # gamma 2 (export.rs:34-38)
+    # reader: PIL-written PNG with filters, then our writer's file
+    big = (rng.random((33, 41, 3)) * 255).astype(np.uint8)
+    Image.fromarray(big).save(tmp_path / "b.png", optimize=True)
+    sb = ra.SceneBuilder()
+    t = sb._call("tex_image_png", C.c_char_p(str(tmp_path / "b.png").encode()))
+    sb.set_world(sb.list([sb.sphere((0, 0, 0), 1.0, sb.lambertian(t))]))
+    d = sb.flatten().contents
+    assert d.n_texel_bytes == big.size and bytes(d.texels[:big.size]) == big.tobytes()
+    Image.fromarray(big[..., 0]).save(tmp_path / "gray.png")
+    with pytest.raises(ra.RtError, match="8-bit"):
+        sb._call("tex_image_png", C.c_char_p(str(tmp_path / "gray.png").encode()))  # texture.rs:103-106
+    with pytest.raises(ra.RtError, match="Failed to find file"):
+        sb._call("tex_image_png", C.c_char_p(b"/nonexistent.png"))
+
+
+def test_partition_strata():
+    from raytracing_amd.distributed import partition_strata
+    for n, w in ((961, 8), (16, 2), (16, 3), (5, 8), (4096, 8)):
+        parts = [partition_strata(n, w, r) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [e - b for b, e in parts]
+        assert max(sizes) - min(sizes) <= 1
+    assert partition_strata(961, 8, 0) == (0, 121) and partition_strata(961, 8, 7) == (841, 961)
