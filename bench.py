@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the render hot path: ray segments/s on the Book-3 Cornell box.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one full frame of the workload: every rank renders the whole 1200x1200 image for
+its own contiguous share of the 961 (= floor(sqrt(1000))^2, camera.rs:341-342) strata, then the
+fp32 film sums are all-reduced (RCCL).  Total work is fixed, so scaling is "strong"; the value
+is (segments traced by all ranks) / (slowest rank's time), in Mrays/s.  A segment is one
+closest-hit query issued by the integrator (one world.hit at camera.rs:444).
+Scene and camera are synthetic (generated in code, seeded); inputs are resident in HBM before
+the timed region starts.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import raytracing_amd as ra  # noqa: E402
+from raytracing_amd import distributed as rdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E, spec
+VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak (packed); 78.6 with scalar v_fma_f32
+
+WORKLOADS = {
+    # name: (scene function, kwargs, estimator mode, description)
+    "c3": (ra.scenes.cornell_book3, dict(width=1200, spp=1000), ra.RT_MODE_BOOK3,
+           "Book-3 Cornell box, glass sphere + light in the light list, 1200x1200, 961 spp, depth 50, mixture PDF"),
+    "c1": (ra.scenes.cornell_main, dict(width=600, spp=20), ra.RT_MODE_REF_EXACT,
+           "main.rs Cornell box as shipped, 600x600, 16 spp, depth 50, light-only sampling"),
+    "c2": (ra.scenes.book1_final, dict(width=1200, spp=500), ra.RT_MODE_BOOK3,
+           "Book-1 final scene, ~488 spheres under a BVH, defocus blur, 1200x675, 484 spp"),
+    "c4": (ra.scenes.book2_final, dict(width=800, spp=10000), ra.RT_MODE_BOOK3,
+           "Book-2 final scene, 800x800, 10000 spp"),
+    "c5": (ra.scenes.stress, dict(n_prims=1_000_000), ra.RT_MODE_BOOK3, "1M random spheres/quads, 3840x2160, 4096 spp"),
+}
+
+# ray-queue bytes one segment moves through each kernel (16-byte records, see rt_kernels.h)
+EXTEND_BYTES = 32 + 16           # read origin/time + direction/origin-ref, write the hit record
+SHADE_READ_BYTES = 32 + 24 + 16  # ray, throughput/pixel, stratum/bounce, hit record
+SHADE_WRITE_BYTES = 56           # a surviving ray's records
+
+
+def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads):
+    """The oracle (C++ f64 restatement of the reference) on a bounded sample of the workload:
+    the full frame for `n_strata_sample` of the strata.  Test infrastructure used as a checker
+    and as the reported baseline only."""
+    from oracle import config_oracle
+    from oracle import oracle_py as orc
+    osb = orc.scene()
+    kw = dict(kw)
+    if scene_fn in (ra.scenes.cornell_main, ra.scenes.cornell_book3):
+        kw["toml_objects"] = config_oracle.toml_objects
+    cam = scene_fn(osb, **kw)
+    t0 = time.perf_counter()
+    _, _, cnt = orc.render(osb, cam, mode=mode, seed=1, stratum_begin=0, stratum_end=n_strata_sample, threads=threads)
+    dt = time.perf_counter() - t0
+    return cnt, dt, cam
+
+
+def flops_per_segment(cnt):
+    """Algorithmic work of one segment from the oracle's counters: 24/box test, 30/sphere test,
+    +30/sphere hit record, 13/quad plane test, +37/quad interior test, 150 for shading."""
+    s = max(cnt["segments"], 1)
+    return (24 * cnt["box_tests"] + 30 * cnt["sphere_tests"] + 30 * cnt["sphere_accepts"] + 13 * cnt["quad_plane_tests"] +
+            37 * cnt["quad_interior_tests"]) / s + 150.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (changes the workload)")
+    ap.add_argument("--pool", type=int, default=0, help="rays in flight per GPU (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-strata", type=int, default=2, help="strata of the full frame the CPU baseline renders")
+    args = ap.parse_args()
+
+    rank, world, local = rdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local)
+
+    scene_fn, kw, mode, desc = WORKLOADS[args.workload]
+    kw = dict(kw)
+    if args.spp:
+        kw["spp"] = args.spp
+    sb = ra.SceneBuilder()
+    cam = scene_fn(sb, **kw)
+    dev = ra.Device(local)
+    dev.upload(sb)
+    rcam = cam.build()
+    n_strata = cam.effective_spp
+    renderer = rdist.DistributedRenderer(dev, local)
+    renderer.bind_film(cam.image_width, cam.image_height)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        renderer.render(rcam, n_strata, rank, world, mode, seed=1, pool_size=args.pool)
+    barrier()
+    seg = 0
+    kernel_ms = np.zeros(4)
+    launches = np.zeros(4)
+    timed = np.zeros(4)
+    cam_rays = 0
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        # every 8th wavefront iteration is bracketed by HIP events (rotating from step to step):
+        # an event is a barrier packet on the stream, timing all of them costs ~10 %
+        _, st = renderer.render(rcam, n_strata, rank, world, mode, seed=1 + step, pool_size=args.pool, time_kernels=True,
+                                time_every=8)
+        if st is not None:
+            seg += st.segments
+            cam_rays += st.camera_rays
+            kernel_ms += np.array(st.kernel_ms)
+            timed += np.array(st.timed_launches)
+            launches += np.array(st.launches)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(seg), float(cam_rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    total_seg, total_cam = float(stats[1]), float(stats[2])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = total_seg / elapsed / 1e6
+    # dominant kernel of this rank, timed with HIP events on the stream the kernels run on
+    names = ["generate", "extend", "shade", "scan"]
+    per_launch_ms = kernel_ms / np.maximum(timed, 1)  # average launch duration, from the timed launches
+    k = int(np.argmax(per_launch_ms * launches))
+    survive = 1.0 - cam_rays / max(seg, 1)  # every path's last segment does not continue
+    bytes_per_seg = {"extend": EXTEND_BYTES, "shade": SHADE_READ_BYTES + survive * SHADE_WRITE_BYTES}.get(names[k], 56.0)
+    avg_launch_ms = per_launch_ms[k]
+    seg_per_launch = seg / max(launches[k], 1)
+    achieved_gbs = bytes_per_seg * seg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    out = {
+        "metric": "ray segments/s", "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "name": args.workload, "image": [cam.image_width, cam.image_height],
+                   "spp": n_strata, "max_depth": cam.max_depth, "estimator": "book3" if mode == ra.RT_MODE_BOOK3 else "ref-exact",
+                   "parallelism": f"spp-split x{world}, one fp32 film all-reduce per step",
+                   "segments_per_step": int(total_seg / args.steps), "segments_per_camera_ray": round(total_seg / max(total_cam, 1), 3)},
+        "time_to_1000spp_s": round(ms_per_step * 1e-3 * 1000.0 / n_strata, 4),
+        "roofline": {"bound": "hbm", "kernel": "k_" + names[k], "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": int(seg_per_launch),
+                     "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]),
+                     "timed_launches": int(timed[k])},
+        "kernel_ms_per_step": {n: round(float(per_launch_ms[i] * launches[i]) / args.steps, 3) for i, n in enumerate(names)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cnt, dt, _ = cpu_baseline(scene_fn, kw, mode, args.cpu_strata, threads=1)
+        fps = flops_per_segment(cnt)
+        out["cpu_baseline"] = {"value": round(cnt["segments"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                               "sample": f"full frame, {args.cpu_strata} of {n_strata} strata ({cnt['camera_rays']} camera rays, "
+                                         f"{cnt['segments']} segments, {dt:.1f} s); C++ f64 restatement of the reference, not the Rust binary"}
+        nthreads = min(16, os.cpu_count() or 1)
+        cnt2, dt2, _ = cpu_baseline(scene_fn, kw, mode, max(args.cpu_strata, 8), threads=nthreads)
+        out["cpu_baseline_all_cores"] = {"value": round(cnt2["segments"] / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": nthreads,
+                                         "kind": "port", "sample": f"full frame, {max(args.cpu_strata, 8)} strata, OpenMP rows, {dt2:.1f} s"}
+        # secondary roofline: fp32 vector peak, algorithmic flops from the oracle's counters
+        tflops = fps * value * 1e6 / 1e12
+        out["valu"] = {"flops_per_segment": round(fps, 1), "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(tflops / VALU_PEAK_TFLOPS, 5)}
+        out["time_to_1000spp_cpu_1core_s"] = round(dt / args.cpu_strata * 1000.0, 1)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

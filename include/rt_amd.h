@@ -164,7 +164,7 @@ typedef struct {
     uint64_t seed;
     uint32_t stratum_begin, stratum_end; /* stratum indices sj*sqrt_spp+si; end = 0 means sqrt_spp^2 */
     uint32_t pool_size;                  /* rays in flight; 0 = default */
-    uint32_t pad;
+    uint32_t time_every;                 /* with RT_FLAG_TIME_KERNELS: time every n-th iteration (0 = all) */
 } rt_render_params;
 
 typedef struct {
@@ -172,8 +172,9 @@ typedef struct {
     uint64_t camera_rays;
     uint64_t dropped;      /* samples skipped because their pdf weight was not finite/positive */
     uint64_t iterations;   /* wavefront iterations of the last rt_render */
-    uint64_t launches[4];  /* generate, extend, shade, other */
-    double kernel_ms[4];   /* summed HIP-event time per kernel class (RT_FLAG_TIME_KERNELS) */
+    uint64_t launches[4];  /* generate, extend, shade, scan */
+    uint64_t timed_launches[4]; /* launches bracketed by HIP events (RT_FLAG_TIME_KERNELS) */
+    double kernel_ms[4];   /* summed HIP-event time of the timed launches, per kernel */
     double render_ms;      /* HIP-event time of the last rt_render, first launch to last */
 } rt_stats;
 

@@ -64,12 +64,12 @@ class RtCamera(C.Structure):
 
 class RtRenderParams(C.Structure):
     _fields_ = [("mode", u32), ("flags", u32), ("seed", u64), ("stratum_begin", u32), ("stratum_end", u32),
-                ("pool_size", u32), ("pad", u32)]
+                ("pool_size", u32), ("time_every", u32)]
 
 
 class RtStats(C.Structure):
     _fields_ = [("segments", u64), ("camera_rays", u64), ("dropped", u64), ("iterations", u64),
-                ("launches", u64 * 4), ("kernel_ms", f64 * 4), ("render_ms", f64)]
+                ("launches", u64 * 4), ("timed_launches", u64 * 4), ("kernel_ms", f64 * 4), ("render_ms", f64)]
 
 
 class CameraBuilderStruct(C.Structure):

@@ -234,8 +234,9 @@ class Stats:
     camera_rays: int = 0
     dropped: int = 0
     iterations: int = 0
-    launches: tuple = (0, 0, 0, 0)
-    kernel_ms: tuple = (0.0, 0.0, 0.0, 0.0)  # generate, extend, shade, scan
+    launches: tuple = (0, 0, 0, 0)           # generate, extend, shade, scan
+    timed_launches: tuple = (0, 0, 0, 0)
+    kernel_ms: tuple = (0.0, 0.0, 0.0, 0.0)  # HIP-event time of the timed launches
     render_ms: float = 0.0
 
 
@@ -290,12 +291,12 @@ class Device:
         self._check(self.lib.rt_film_clear(self.h), "rt_film_clear")
 
     def render(self, cam: RtCamera, mode=RT_MODE_REF_EXACT, seed=1, stratum_begin=0, stratum_end=0, pool_size=0,
-               time_kernels=False):
+               time_kernels=False, time_every=0):
         """Adds strata [begin, end) of every pixel into the film (camera.rs:386-401)."""
         p = RtRenderParams()
         p.mode, p.seed = mode, seed
         p.flags = RT_FLAG_TIME_KERNELS if time_kernels else 0
-        p.stratum_begin, p.stratum_end, p.pool_size = stratum_begin, stratum_end, pool_size
+        p.stratum_begin, p.stratum_end, p.pool_size, p.time_every = stratum_begin, stratum_end, pool_size, time_every
         self._check(self.lib.rt_render(self.h, C.byref(cam), C.byref(p)), "rt_render")
         self.width, self.height = cam.image_width, cam.image_height
         return self.stats()
@@ -303,7 +304,8 @@ class Device:
     def stats(self) -> Stats:
         s = RtStats()
         self._check(self.lib.rt_get_stats(self.h, C.byref(s)), "rt_get_stats")
-        return Stats(s.segments, s.camera_rays, s.dropped, s.iterations, tuple(s.launches), tuple(s.kernel_ms), s.render_ms)
+        return Stats(s.segments, s.camera_rays, s.dropped, s.iterations, tuple(s.launches), tuple(s.timed_launches),
+                     tuple(s.kernel_ms), s.render_ms)
 
     def film(self, scale=1.0):
         """(H, W, 3) float32 = film sums * scale."""

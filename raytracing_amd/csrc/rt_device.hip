@@ -279,6 +279,7 @@ struct Timer {
         }
         int i = int(h->ev_used++);
         h->ev_pool[i].cls = cls;
+        h->stats.timed_launches[cls]++;
         (void)hipEventRecord(h->ev_pool[i].a, h->stream);
         return i;
     }
@@ -552,7 +553,10 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     const uint32_t k0 = uint32_t(p->seed), k1 = uint32_t(p->seed >> 32);
     const Film film{h->film, h->film + dc.npix, h->film + 2 * size_t(dc.npix)};
     const dim3 grid(n_chunks / (BLOCK / WAVE)), block(BLOCK);
-    Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
+    const bool timing = (p->flags & RT_FLAG_TIME_KERNELS) != 0;
+    const uint32_t time_every = p->time_every ? p->time_every : 1u;
+    Timer tm{h, false};
+    uint64_t iter_no = p->seed; // rotate which iterations are timed from render to render
 
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
     const int ITERS_PER_POLL = 8;
@@ -563,6 +567,7 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     const unsigned long long max_iters = total / (size_t(n_chunks) * cap) * (dc.max_depth + 1ull) + 4ull * dc.max_depth + 64;
     while (!done) {
         for (int it = 0; it < ITERS_PER_POLL; ++it) {
+            tm.on = timing && (iter_no++ % time_every) == 0;
             int e = tm.begin(3);
             k_scan<<<1, 1024, 0, h->stream>>>(h->q, h->d_ctrl);
             tm.end(e);
