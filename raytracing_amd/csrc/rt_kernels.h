@@ -329,16 +329,62 @@ __device__ __forceinline__ void traverse(const DScene &sc, V3 o, V3 d, float tim
     }
 }
 
-// Flat world (a HittableVec of primitives, e.g. main.rs:30-69): the ref list is uniform
-// across the wave, so primitive records come through scalar loads and no stack is needed.
+// Read-only scene records through the constant address space: with a wave-uniform address the
+// backend selects scalar loads (s_load_dwordx4..x16), the record lands in SGPRs and feeds the
+// VALU directly -- no vector-memory instruction and no VGPRs per primitive.  Only for arrays
+// nothing writes while a kernel runs.
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const RT_CONST_AS T *as_uniform(const T *p) {
+    return reinterpret_cast<const RT_CONST_AS T *>(reinterpret_cast<uintptr_t>(p));
+}
+
+// Flat world (a HittableVec of primitives, e.g. main.rs:30-69): every lane walks the same list
+// in the list's order, so each primitive is one scalar record applied to 64 rays.  The quad
+// test is written without branches: in a 64-lane wave some lane almost always passes the plane
+// test, so skipping the interior test saves nothing and costs exec-mask bookkeeping.
 __device__ __forceinline__ void scan_flat(const DScene &sc, uint32_t first, uint32_t count, V3 o, V3 d,
                                           float time, float tlo, float thi, uint32_t origin_ref,
                                           const RayCtx &rc, Best &best) {
     best.t = thi;
     best.ref = RT_REF_NONE;
     best.u = best.v = 0.f;
+    const RT_CONST_AS uint32_t *refs = as_uniform(sc.refs) + first;
+    // Quads first, then the rest, each group in list order.  The outcome equals one pass in
+    // list order: quads accept t <= closest (a later quad wins a tie), spheres need
+    // t < closest (an earlier hit wins), so a quad wins a quad/sphere tie in either order.
     for (uint32_t k = 0; k < count; ++k) {
-        uint32_t r = sc.refs[first + k];
+        const uint32_t r = refs[k];
+        if ((r >> RT_REF_KIND_SHIFT) != RT_KIND_QUAD) continue;
+        const RT_CONST_AS float *Q =
+            as_uniform(reinterpret_cast<const float *>(sc.quads)) + 24 * size_t(r & RT_REF_INDEX_MASK);
+        // record: q.xyz,D | n.xyz,area | avec.xyz,shape | bvec.xyz,mat   (hittable.rs:341-371)
+        const V3 n = {Q[4], Q[5], Q[6]};
+        const float denom = dot(n, d);
+        const V3 qo = {Q[0] - o.x, Q[1] - o.y, Q[2] - o.z};
+        const float tt = dot(n, qo) * __builtin_amdgcn_rcpf(denom); // v_rcp_f32: 1 ulp
+        const V3 ph = fma3(d, tt, -qo);
+        const float alpha = dot(ph, V3{Q[8], Q[9], Q[10]});
+        const float beta = dot(ph, V3{Q[12], Q[13], Q[14]});
+        const float q2w = Q[11];
+        const uint32_t shape = fbits(q2w);
+        bool inside = fminf(alpha, beta) >= 0.0f;
+        if (shape == RT_SHAPE_PARALLELOGRAM) {
+            inside &= fmaxf(alpha, beta) <= 1.0f;
+        } else if (shape == RT_SHAPE_TRIANGLE) {
+            inside &= !((alpha + beta) > 1.0f);
+        } else {
+            const float ac = 0.5f - alpha, bc = 0.5f - beta;
+            inside &= !(sqrtf(ac * ac + bc * bc) > 0.5f);
+        }
+        const bool ok = inside & (fabsf(denom) >= 1e-8f) & (tt >= tlo) & (tt <= best.t) & (r != origin_ref);
+        best.t = ok ? tt : best.t;
+        best.ref = ok ? r : best.ref;
+        best.u = ok ? alpha : best.u;
+        best.v = ok ? beta : best.v;
+    }
+    for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t r = refs[k];
+        if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) continue;
         test_prim(sc, r, o, d, time, tlo, origin_ref, rc, best);
     }
 }
