@@ -157,14 +157,18 @@ typedef struct {
 #define RT_MODE_REF_EXACT 0u /* estimator exactly as shipped, camera.rs:455-470 */
 #define RT_MODE_BOOK3 1u     /* mixture estimator built from pdf.rs/onb.rs, specular bypass */
 
-#define RT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (see rt_stats) */
+#define RT_FLAG_TIME_KERNELS 1u /* bracket kernels with HIP events (see rt_stats) */
+#define RT_FLAG_WAVEFRONT 2u    /* ray-queue pipeline (scan/generate/extend/shade launches) instead of
+                                 * the persistent path kernel; same image for the same seed */
 typedef struct {
     uint32_t mode;
     uint32_t flags;
     uint64_t seed;
     uint32_t stratum_begin, stratum_end; /* stratum indices sj*sqrt_spp+si; end = 0 means sqrt_spp^2 */
-    uint32_t pool_size;                  /* rays in flight; 0 = default */
-    uint32_t time_every;                 /* with RT_FLAG_TIME_KERNELS: time every n-th iteration (0 = all) */
+    uint32_t pool_size;                  /* wavefront: rays in flight; 0 = default */
+    uint32_t time_every;                 /* wavefront + RT_FLAG_TIME_KERNELS: time every n-th iteration (0 = all) */
+    uint32_t refill_min;                 /* persistent: idle lanes of a wave before it takes new samples; 0 = default */
+    uint32_t waves_per_simd;             /* persistent: resident waves per SIMD to launch; 0 = all that fit */
 } rt_render_params;
 
 typedef struct {
@@ -172,9 +176,9 @@ typedef struct {
     uint64_t camera_rays;
     uint64_t dropped;      /* samples skipped because their pdf weight was not finite/positive */
     uint64_t iterations;   /* wavefront iterations of the last rt_render */
-    uint64_t launches[4];  /* generate, extend, shade, scan */
-    uint64_t timed_launches[4]; /* launches bracketed by HIP events (RT_FLAG_TIME_KERNELS) */
-    double kernel_ms[4];   /* summed HIP-event time of the timed launches, per kernel */
+    uint64_t launches[5];  /* generate, extend, shade, scan, paths (the persistent kernel) */
+    uint64_t timed_launches[5]; /* launches bracketed by HIP events (RT_FLAG_TIME_KERNELS) */
+    double kernel_ms[5];   /* summed HIP-event time of the timed launches, per kernel */
     double render_ms;      /* HIP-event time of the last rt_render, first launch to last */
 } rt_stats;
 

@@ -4,7 +4,7 @@ The compute path is librt_amd.so: hand-written HIP kernels for gfx950 behind the
 include/rt_amd.h, plus the C++ host layer that mirrors the reference's scene/camera/config API.
 This package only binds it; importing fails if the library has not been built.
 """
-from ._ffi import RT_FLAG_TIME_KERNELS, RT_MODE_BOOK3, RT_MODE_REF_EXACT  # noqa: F401
+from ._ffi import RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT, RT_MODE_BOOK3, RT_MODE_REF_EXACT  # noqa: F401
 from .api import (CameraSettings, Device, RtError, SceneBuilder, Stats, device_count,  # noqa: F401
                   SHAPE_DISC, SHAPE_PARALLELOGRAM, SHAPE_TRIANGLE)
 from . import scenes  # noqa: F401

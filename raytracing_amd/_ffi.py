@@ -64,12 +64,12 @@ class RtCamera(C.Structure):
 
 class RtRenderParams(C.Structure):
     _fields_ = [("mode", u32), ("flags", u32), ("seed", u64), ("stratum_begin", u32), ("stratum_end", u32),
-                ("pool_size", u32), ("time_every", u32)]
+                ("pool_size", u32), ("time_every", u32), ("refill_min", u32), ("waves_per_simd", u32)]
 
 
 class RtStats(C.Structure):
     _fields_ = [("segments", u64), ("camera_rays", u64), ("dropped", u64), ("iterations", u64),
-                ("launches", u64 * 4), ("timed_launches", u64 * 4), ("kernel_ms", f64 * 4), ("render_ms", f64)]
+                ("launches", u64 * 5), ("timed_launches", u64 * 5), ("kernel_ms", f64 * 5), ("render_ms", f64)]
 
 
 class CameraBuilderStruct(C.Structure):
@@ -81,6 +81,7 @@ class CameraBuilderStruct(C.Structure):
 
 RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
 RT_FLAG_TIME_KERNELS = 1
+RT_FLAG_WAVEFRONT = 2
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
 RT_NODE_LEAF = 0xFFFFFFFF
 

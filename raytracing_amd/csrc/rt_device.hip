@@ -32,7 +32,7 @@ struct rt_handle {
     DScene sc{};
     bool have_scene = false;
     bool flat = false;
-    uint32_t flat_first = 0, flat_count = 0, has_media = 0, n_prims = 0;
+    uint32_t has_media = 0, n_prims = 0;
     bool has_specular = false;
     uint32_t n_textures = 0;
     std::vector<uint32_t> prim_to_ref; // user-visible primitive id -> ref (parity hook)
@@ -297,6 +297,69 @@ void drain_timers(rt_handle *h) {
     h->ev_used = 0;
 }
 
+// One launch of the persistent path kernel: as many blocks as the device keeps resident.
+template <int MODE, bool FLAT, int OCC>
+int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
+                 unsigned long long total) {
+    auto kernel = k_paths<MODE, FLAT, OCC>;
+    int per_cu = 0, n_cu = 0;
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
+    RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
+    if (p->waves_per_simd && int(p->waves_per_simd) < per_cu) per_cu = int(p->waves_per_simd); // a block is one wave per SIMD
+    unsigned long long waves = (unsigned long long)per_cu * n_cu * (BLOCK / WAVE);
+    // samples a wave takes from the global counter at a time: large enough that the counter is
+    // idle, small enough that the last waves to finish hold little work
+    unsigned long long grab = total / (waves * 8ull);
+    grab = grab > 1024 ? 1024 : (grab < 64 ? 64 : (grab & ~63ull));
+    unsigned long long blocks_needed = (total + grab * (BLOCK / WAVE) - 1) / (grab * (BLOCK / WAVE));
+    unsigned long long blocks = (unsigned long long)per_cu * n_cu;
+    if (blocks > blocks_needed) blocks = blocks_needed;
+    uint32_t refill_min = p->refill_min ? p->refill_min : 16u;
+    if (refill_min > uint32_t(WAVE)) refill_min = WAVE;
+    Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
+    int e = tm.begin(4);
+    kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), 0, h->stream>>>(h->sc, dc, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
+                                                                h->d_ctrl, h->has_media,
+                                                                uint32_t(grab), refill_min);
+    tm.end(e);
+    RT_HIP(hipGetLastError());
+    h->stats.launches[4]++;
+    return 0;
+}
+
+int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
+                      unsigned long long total) {
+    RT_HIP(hipEventRecord(h->ev_begin, h->stream));
+    int rc;
+    const bool exact = p->mode == RT_MODE_REF_EXACT;
+#define RT_PATHS(OCC)                                                                                              \
+    (exact ? (h->flat ? launch_paths<RT_MODE_REF_EXACT, true, OCC>(h, dc, p, film, total)                           \
+                      : launch_paths<RT_MODE_REF_EXACT, false, OCC>(h, dc, p, film, total))                         \
+           : (h->flat ? launch_paths<RT_MODE_BOOK3, true, OCC>(h, dc, p, film, total)                               \
+                      : launch_paths<RT_MODE_BOOK3, false, OCC>(h, dc, p, film, total)))
+    switch (p->waves_per_simd) {
+    case 4: rc = RT_PATHS(4); break;
+    case 5: rc = RT_PATHS(5); break;
+    case 6: rc = RT_PATHS(6); break;
+    default: rc = RT_PATHS(1); break;
+    }
+#undef RT_PATHS
+    if (rc) return rc;
+    RT_HIP(hipEventRecord(h->ev_end, h->stream));
+    RT_HIP(hipMemcpyAsync(&h->h_ctrl[0], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
+    RT_HIP(hipStreamSynchronize(h->stream));
+    const Ctrl &fin = h->h_ctrl[0];
+    h->stats.segments = fin.segments;
+    h->stats.camera_rays = fin.camera_rays;
+    h->stats.dropped = fin.dropped;
+    float ms = 0.f;
+    RT_HIP(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+    h->stats.render_ms = ms;
+    drain_timers(h);
+    return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -396,9 +459,56 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     const rt_quad *dq;
     const rt_sphere *ds;
     const float *dnv;
+    // device copy of the materials: a SolidColor texture is folded into the material record
+    // (albedo + pad = 1) so that shading such a surface does not chase the texture record
+    std::vector<rt_material> mats(s->materials, s->materials + s->n_materials);
+    for (rt_material &m : mats) {
+        m.pad = 0;
+        const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LIGHT || m.type == RT_MAT_ISOTROPIC;
+        if (textured && s->textures[m.tex].type == RT_TEX_SOLID) {
+            std::memcpy(m.albedo, s->textures[m.tex].color, sizeof(m.albedo));
+            m.pad = 1;
+        }
+    }
+    // A world that is one list of primitives takes the stack-free scan: its quads packed in
+    // list order for scalar loads, everything else by reference.
+    std::vector<float> flat_quads;
+    std::vector<uint32_t> flat_other;
+    h->flat = false;
+    {
+        uint32_t rk = s->root >> RT_REF_KIND_SHIFT, ri = s->root & RT_REF_INDEX_MASK;
+        if (rk == RT_KIND_NODE && s->nodes[ri].right == RT_NODE_LEAF && s->nodes[ri].count <= 64) {
+            bool only_prims = true;
+            for (uint32_t k = 0; k < s->nodes[ri].count; ++k)
+                if ((s->refs[s->nodes[ri].left + k] >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) only_prims = false;
+            if (only_prims) {
+                h->flat = true;
+                for (uint32_t k = 0; k < s->nodes[ri].count; ++k) {
+                    const uint32_t r = s->refs[s->nodes[ri].left + k];
+                    if ((r >> RT_REF_KIND_SHIFT) != RT_KIND_QUAD) {
+                        flat_other.push_back(r);
+                        continue;
+                    }
+                    const rt_quad &q = s->quads[r & RT_REF_INDEX_MASK];
+                    float rec[16] = {q.q[0], q.q[1], q.q[2], 0.f, q.n[0], q.n[1], q.n[2], 0.f,
+                                     q.avec[0], q.avec[1], q.avec[2], 0.f, q.bvec[0], q.bvec[1], q.bvec[2], 0.f};
+                    std::memcpy(&rec[3], &r, 4);
+                    std::memcpy(&rec[7], &q.mat, 4);
+                    std::memcpy(&rec[11], &q.shape, 4);
+                    flat_quads.insert(flat_quads.end(), rec, rec + 16);
+                }
+            }
+        }
+    }
+    d.n_flat_quads = uint32_t(flat_quads.size() / 16);
+    // the scan requests records in pairs, one pair ahead: pad with records that cannot hit
+    flat_quads.resize((size_t(d.n_flat_quads) + 3) / 2 * 2 * 16, 0.0f);
+    d.n_flat_other = uint32_t(flat_other.size());
     if (upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, s->spheres, s->n_spheres, &ds) ||
-        upload(h, s->media, s->n_media, &d.media) || upload(h, s->materials, s->n_materials, &d.mats) ||
+        upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) ||
+        upload(h, flat_other.data(), flat_other.size(), &d.flat_other) ||
+        upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
         upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) ||
         upload(h, s->texels, s->n_texel_bytes, &d.texels) || upload(h, s->noise_vec, size_t(s->n_noise) * 1024, &dnv) ||
         upload(h, s->noise_perm, size_t(s->n_noise) * 768, &d.noise_perm)) {
@@ -428,20 +538,6 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     for (uint32_t i = 0; i < s->n_quads; ++i) note(s->quads[i].prim_id, (RT_KIND_QUAD << RT_REF_KIND_SHIFT) | i);
     for (uint32_t i = 0; i < s->n_spheres; ++i) note(s->spheres[i].prim_id, (RT_KIND_SPHERE << RT_REF_KIND_SHIFT) | i);
     for (uint32_t i = 0; i < s->n_media; ++i) note(s->media[i].prim_id, (RT_KIND_MEDIUM << RT_REF_KIND_SHIFT) | i);
-    // A world that is one list of primitives takes the stack-free kernel.
-    h->flat = false;
-    h->flat_first = h->flat_count = 0;
-    uint32_t rk = s->root >> RT_REF_KIND_SHIFT, ri = s->root & RT_REF_INDEX_MASK;
-    if (rk == RT_KIND_NODE && s->nodes[ri].right == RT_NODE_LEAF) {
-        bool only_prims = true;
-        for (uint32_t k = 0; k < s->nodes[ri].count; ++k)
-            if ((s->refs[s->nodes[ri].left + k] >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) only_prims = false;
-        if (only_prims && s->nodes[ri].count <= 64) {
-            h->flat = true;
-            h->flat_first = s->nodes[ri].left;
-            h->flat_count = s->nodes[ri].count;
-        }
-    }
     return 0;
 }
 
@@ -534,6 +630,16 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     std::memset(&h->stats, 0, sizeof(h->stats));
     if (total == 0) return 0;
 
+    Ctrl init{};
+    init.total_samples = total;
+    h->h_ctrl[0] = init;
+    RT_HIP(hipMemcpyAsync(h->d_ctrl, &h->h_ctrl[0], sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
+    RT_HIP(hipStreamSynchronize(h->stream)); // h_ctrl[0] is reused below
+
+    const uint32_t k0 = uint32_t(p->seed), k1 = uint32_t(p->seed >> 32);
+    const Film film{h->film, h->film + dc.npix, h->film + 2 * size_t(dc.npix)};
+    if (!(p->flags & RT_FLAG_WAVEFRONT)) return render_persistent(h, dc, p, film, total);
+
     // pool geometry: chunks of 512 rays, one wave each
     const uint32_t cap = 512;
     unsigned long long pool = p->pool_size ? p->pool_size : (1ull << 22);
@@ -543,15 +649,7 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     n_chunks = (n_chunks + 3u) & ~3u;
     if (ensure_queue(h, n_chunks, cap)) return -1;
 
-    Ctrl init{};
-    init.total_samples = total;
-    h->h_ctrl[0] = init;
-    RT_HIP(hipMemcpyAsync(h->d_ctrl, &h->h_ctrl[0], sizeof(Ctrl), hipMemcpyHostToDevice, h->stream));
     RT_HIP(hipMemsetAsync(h->q.count, 0, n_chunks * sizeof(uint32_t), h->stream));
-    RT_HIP(hipStreamSynchronize(h->stream)); // h_ctrl[0] is reused below
-
-    const uint32_t k0 = uint32_t(p->seed), k1 = uint32_t(p->seed >> 32);
-    const Film film{h->film, h->film + dc.npix, h->film + 2 * size_t(dc.npix)};
     const dim3 grid(n_chunks / (BLOCK / WAVE)), block(BLOCK);
     const bool timing = (p->flags & RT_FLAG_TIME_KERNELS) != 0;
     const uint32_t time_every = p->time_every ? p->time_every : 1u;
@@ -576,9 +674,9 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
             tm.end(e);
             e = tm.begin(1);
             if (h->flat)
-                k_extend<true><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, h->flat_first, h->flat_count, h->has_media);
+                k_extend<true><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, h->has_media);
             else
-                k_extend<false><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, 0u, 0u, h->has_media);
+                k_extend<false><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, h->has_media);
             tm.end(e);
             e = tm.begin(2);
             if (p->mode == RT_MODE_REF_EXACT)
@@ -655,10 +753,9 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (e == hipSuccess) {
         dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
         if (h->flat)
-            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, h->flat_first,
-                                                                   h->flat_count, d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         else
-            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, 0u, 0u, d_i,
+            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
                                                                     d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         e = hipGetLastError();
     }

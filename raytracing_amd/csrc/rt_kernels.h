@@ -36,7 +36,11 @@ struct DScene {
     const uint8_t *texels;
     const float4 *noise_vec;
     const int *noise_perm;
-    uint32_t root, n_lights, lights_kind, n_nodes;
+    // a world that is one list of primitives: its quads packed in list order, 16 floats each
+    // (q.xyz ref | n.xyz mat | avec.xyz shape | bvec.xyz -), and the refs of everything else
+    const float *flat_quads;
+    const uint32_t *flat_other;
+    uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_other;
 };
 
 struct DCamera {
@@ -71,20 +75,40 @@ struct Best {
     float t;
     uint32_t ref;
     float u, v;
+    uint32_t mat; // material id when the scan already had the record in hand, else RT_REF_NONE
 };
+
+// Read-only scene records through the constant address space: with a wave-uniform address the
+// backend selects scalar loads (s_load_dwordx4..x16), the record lands in SGPRs and feeds the
+// VALU directly -- no vector-memory instruction and no VGPRs per primitive.  Only for arrays
+// nothing writes while a kernel runs.
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const RT_CONST_AS T *as_uniform(const T *p) {
+    return reinterpret_cast<const RT_CONST_AS T *>(reinterpret_cast<uintptr_t>(p));
+}
+
+// A 16-byte record element either per lane (vector load) or wave-uniform (scalar load).
+template <bool UNIFORM> __device__ __forceinline__ float4 load4(const float4 *base, size_t i) {
+    if (UNIFORM) {
+        const RT_CONST_AS float *p = as_uniform(reinterpret_cast<const float *>(base)) + 4 * i;
+        return make_float4(p[0], p[1], p[2], p[3]);
+    }
+    return base[i];
+}
 
 // Parallelogram / Triangle / Disc (hittable.rs:341-371, 520-551, 641-672).
 // t in [tlo, thi] closed (Interval::contains).
+template <bool UNIFORM = false>
 __device__ __forceinline__ bool hit_quad(const float4 *__restrict__ Q, V3 o, V3 d, float tlo, float thi,
                                          float &t, float &a, float &b) {
-    float4 q0 = Q[0], q1 = Q[1];
+    float4 q0 = load4<UNIFORM>(Q, 0), q1 = load4<UNIFORM>(Q, 1);
     V3 n = mk(q1);
     float denom = dot(n, d);
     if (fabsf(denom) < 1e-8f) return false;
     V3 qo = mk(q0) - o;
     float tt = dot(n, qo) / denom; // (D - n.o)/denom with the subtraction done first
     if (!(tt >= tlo && tt <= thi)) return false;
-    float4 q2 = Q[2], q3 = Q[3];
+    float4 q2 = load4<UNIFORM>(Q, 2), q3 = load4<UNIFORM>(Q, 3);
     V3 ph = fma3(d, tt, -qo);
     float alpha = dot(ph, mk(q2));
     float beta = dot(ph, mk(q3));
@@ -122,10 +146,9 @@ __device__ __forceinline__ void two_sum(float a, float b, float &s, float &e) {
     float bb = s - a;
     e = (a - (s - bb)) + (b - bb);
 }
-__device__ __forceinline__ bool hit_sphere(const float4 *__restrict__ S, V3 o, V3 d, float time, float tlo,
-                                           float thi, bool from_self, float &t) {
+__device__ __forceinline__ bool hit_sphere(float4 s0, float4 s1, V3 o, V3 d, float time, float tlo, float thi,
+                                           bool from_self, float &t) {
 #pragma clang fp contract(off) // the error terms below must see the same roundings as the sums
-    float4 s0 = S[0], s1 = S[1];
     V3 center = fma3(mk(s1), time, mk(s0));
     V3 oc, ol; // oc + ol = centre - o exactly
     two_sum(center.x, -o.x, oc.x, ol.x);
@@ -172,6 +195,11 @@ __device__ __forceinline__ bool hit_sphere(const float4 *__restrict__ S, V3 o, V
     }
     t = root;
     return true;
+}
+template <bool UNIFORM = false>
+__device__ __forceinline__ bool hit_sphere(const float4 *__restrict__ S, V3 o, V3 d, float time, float tlo,
+                                           float thi, bool from_self, float &t) {
+    return hit_sphere(load4<UNIFORM>(S, 0), load4<UNIFORM>(S, 1), o, d, time, tlo, thi, from_self, t);
 }
 
 // hittable.rs:150-162; u_shift undoes a baked RotateY (longitude is taken in the sphere's frame)
@@ -235,6 +263,7 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, uint32_t idx, V3 o,
     return true;
 }
 
+template <bool UNIFORM = false>
 __device__ __forceinline__ void test_prim(const DScene &sc, uint32_t r, V3 o, V3 d, float time, float tlo,
                                           uint32_t origin_ref, const RayCtx &rc, Best &best) {
     uint32_t kind = r >> RT_REF_KIND_SHIFT, idx = r & RT_REF_INDEX_MASK;
@@ -244,9 +273,9 @@ __device__ __forceinline__ void test_prim(const DScene &sc, uint32_t r, V3 o, V3
         // a ray leaving a planar primitive cannot meet it again; the reference rejects the
         // t ~ 0 root through its 0.001 lower bound, which fp32 at scene scale cannot resolve
         if (r == origin_ref) return;
-        h = hit_quad(sc.quads + 6 * idx, o, d, tlo, best.t, t, a, b);
+        h = hit_quad<UNIFORM>(sc.quads + 6 * idx, o, d, tlo, best.t, t, a, b);
     } else if (kind == RT_KIND_SPHERE) {
-        h = hit_sphere(sc.spheres + 3 * idx, o, d, time, tlo, best.t, r == origin_ref, t);
+        h = hit_sphere<UNIFORM>(sc.spheres + 3 * idx, o, d, time, tlo, best.t, r == origin_ref, t);
     } else {
         h = hit_medium(sc, idx, o, d, time, tlo, best.t, rc, t);
     }
@@ -255,6 +284,7 @@ __device__ __forceinline__ void test_prim(const DScene &sc, uint32_t r, V3 o, V3
         best.ref = r;
         best.u = a;
         best.v = b;
+        best.mat = RT_REF_NONE;
     }
 }
 
@@ -278,7 +308,7 @@ __device__ __forceinline__ void traverse(const DScene &sc, V3 o, V3 d, float tim
                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *stack,
                                          const rt_node *lnodes, Best &best) {
     best.t = thi;
-    best.ref = RT_REF_NONE;
+    best.ref = best.mat = RT_REF_NONE;
     best.u = best.v = 0.f;
     V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
     int sp = 0;
@@ -329,64 +359,73 @@ __device__ __forceinline__ void traverse(const DScene &sc, V3 o, V3 d, float tim
     }
 }
 
-// Read-only scene records through the constant address space: with a wave-uniform address the
-// backend selects scalar loads (s_load_dwordx4..x16), the record lands in SGPRs and feeds the
-// VALU directly -- no vector-memory instruction and no VGPRs per primitive.  Only for arrays
-// nothing writes while a kernel runs.
-#define RT_CONST_AS __attribute__((address_space(4)))
-template <typename T> __device__ __forceinline__ const RT_CONST_AS T *as_uniform(const T *p) {
-    return reinterpret_cast<const RT_CONST_AS T *>(reinterpret_cast<uintptr_t>(p));
+// Flat world (a HittableVec of primitives, e.g. main.rs:30-69): every lane walks the same list,
+// so each primitive is one scalar record applied to 64 rays.  The quad test is written without
+// branches: in a 64-lane wave some lane almost always passes the plane test, so skipping the
+// interior test saves nothing and costs exec-mask bookkeeping.  The next record is requested
+// before the current one is used; scalar loads return out of order behind one counter, so the
+// wait at the end of an iteration is the only one.
+// Quads are scanned first, then the rest, each group in list order.  The outcome equals one pass
+// in list order: quads accept t <= closest (a later quad wins a tie), spheres need t < closest
+// (an earlier hit wins), so a quad wins a quad/sphere tie in either order.
+struct QuadRec {
+    float f[16];
+};
+__device__ __forceinline__ QuadRec load_quad_rec(const RT_CONST_AS float *p) {
+    QuadRec r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.f[i] = p[i];
+    return r;
 }
-
-// Flat world (a HittableVec of primitives, e.g. main.rs:30-69): every lane walks the same list
-// in the list's order, so each primitive is one scalar record applied to 64 rays.  The quad
-// test is written without branches: in a 64-lane wave some lane almost always passes the plane
-// test, so skipping the interior test saves nothing and costs exec-mask bookkeeping.
-__device__ __forceinline__ void scan_flat(const DScene &sc, uint32_t first, uint32_t count, V3 o, V3 d,
-                                          float time, float tlo, float thi, uint32_t origin_ref,
-                                          const RayCtx &rc, Best &best) {
+__device__ __forceinline__ void scan_flat(const DScene &sc, V3 o, V3 d, float time, float tlo, float thi,
+                                          uint32_t origin_ref, const RayCtx &rc, Best &best) {
     best.t = thi;
-    best.ref = RT_REF_NONE;
+    best.ref = best.mat = RT_REF_NONE;
     best.u = best.v = 0.f;
-    const RT_CONST_AS uint32_t *refs = as_uniform(sc.refs) + first;
-    // Quads first, then the rest, each group in list order.  The outcome equals one pass in
-    // list order: quads accept t <= closest (a later quad wins a tie), spheres need
-    // t < closest (an earlier hit wins), so a quad wins a quad/sphere tie in either order.
-    for (uint32_t k = 0; k < count; ++k) {
-        const uint32_t r = refs[k];
-        if ((r >> RT_REF_KIND_SHIFT) != RT_KIND_QUAD) continue;
-        const RT_CONST_AS float *Q =
-            as_uniform(reinterpret_cast<const float *>(sc.quads)) + 24 * size_t(r & RT_REF_INDEX_MASK);
-        // record: q.xyz,D | n.xyz,area | avec.xyz,shape | bvec.xyz,mat   (hittable.rs:341-371)
-        const V3 n = {Q[4], Q[5], Q[6]};
+    const RT_CONST_AS float *Q = as_uniform(sc.flat_quads);
+    const uint32_t nq = sc.n_flat_quads;
+    auto test = [&](const QuadRec &rec) { // hittable.rs:341-371
+        const float *c = rec.f;
+        const uint32_t r = fbits(c[3]);
+        const V3 n = {c[4], c[5], c[6]};
         const float denom = dot(n, d);
-        const V3 qo = {Q[0] - o.x, Q[1] - o.y, Q[2] - o.z};
+        const V3 qo = {c[0] - o.x, c[1] - o.y, c[2] - o.z};
         const float tt = dot(n, qo) * __builtin_amdgcn_rcpf(denom); // v_rcp_f32: 1 ulp
         const V3 ph = fma3(d, tt, -qo);
-        const float alpha = dot(ph, V3{Q[8], Q[9], Q[10]});
-        const float beta = dot(ph, V3{Q[12], Q[13], Q[14]});
-        const float q2w = Q[11];
-        const uint32_t shape = fbits(q2w);
-        bool inside = fminf(alpha, beta) >= 0.0f;
-        if (shape == RT_SHAPE_PARALLELOGRAM) {
-            inside &= fmaxf(alpha, beta) <= 1.0f;
-        } else if (shape == RT_SHAPE_TRIANGLE) {
-            inside &= !((alpha + beta) > 1.0f);
-        } else {
-            const float ac = 0.5f - alpha, bc = 0.5f - beta;
-            inside &= !(sqrtf(ac * ac + bc * bc) > 0.5f);
-        }
+        const float alpha = dot(ph, V3{c[8], c[9], c[10]});
+        const float beta = dot(ph, V3{c[12], c[13], c[14]});
+        const uint32_t shape = fbits(c[11]);
+        // interior rules (hittable.rs:360, 539, 660); sqrt(x) > 0.5 <=> x > 0.25 exactly.
+        // One measure per shape, selected by the uniform shape code: no branches in the loop.
+        const float ac = 0.5f - alpha, bc = 0.5f - beta;
+        const float m_par = fmaxf(alpha, beta), m_tri = alpha + beta, m_disc = fmaf(ac, ac, bc * bc);
+        const float measure = shape == RT_SHAPE_PARALLELOGRAM ? m_par : (shape == RT_SHAPE_TRIANGLE ? m_tri : m_disc);
+        const float limit = shape == RT_SHAPE_DISC ? 0.25f : 1.0f;
+        const bool inside = (fminf(alpha, beta) >= 0.0f) & !(measure > limit);
         const bool ok = inside & (fabsf(denom) >= 1e-8f) & (tt >= tlo) & (tt <= best.t) & (r != origin_ref);
         best.t = ok ? tt : best.t;
         best.ref = ok ? r : best.ref;
         best.u = ok ? alpha : best.u;
         best.v = ok ? beta : best.v;
+        best.mat = ok ? fbits(c[7]) : best.mat;
+    };
+    // Two records in turn, so that no register copies sit between a request and its wait.  The
+    // packed array ends with an all-zero record after an odd count (a zero normal never hits)
+    // and one more after that, so requests need no bounds and the loop body has no branch.
+    // The asm statements keep each request where it is written.
+    if (nq) {
+        QuadRec a = load_quad_rec(Q);
+        for (uint32_t k = 0; k < nq; k += 2) {
+            const QuadRec b = load_quad_rec(Q + 16 * size_t(k + 1));
+            asm volatile("" ::: "memory");
+            test(a);
+            a = load_quad_rec(Q + 16 * size_t(k + 2));
+            asm volatile("" ::: "memory");
+            test(b);
+        }
     }
-    for (uint32_t k = 0; k < count; ++k) {
-        const uint32_t r = refs[k];
-        if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) continue;
-        test_prim(sc, r, o, d, time, tlo, origin_ref, rc, best);
-    }
+    const RT_CONST_AS uint32_t *other = as_uniform(sc.flat_other);
+    for (uint32_t k = 0; k < sc.n_flat_other; ++k) test_prim<true>(sc, other[k], o, d, time, tlo, origin_ref, rc, best);
 }
 
 // ------------------------------------------------------------------ textures (texture.rs)
@@ -453,17 +492,18 @@ __device__ __forceinline__ V3 tex_value(const DScene &sc, uint32_t id, float u, 
 // ------------------------------------------------------------------ lights (hittable.rs:377-395)
 // direction to a random point of light `r`, unnormalised (Parallelogram::random), or towards
 // the visible cap of a sphere
+// UNIFORM: r is the same in every lane, so the light's record comes through scalar loads.
+template <bool UNIFORM>
 __device__ __forceinline__ V3 light_random(const DScene &sc, uint32_t r, V3 p, Rng &rng) {
     uint32_t idx = r & RT_REF_INDEX_MASK;
     if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
         const float4 *Q = sc.quads + 6 * idx;
         float a = rng.next();
         float b = rng.next();
-        V3 lp = fma3(mk(Q[5]), b, fma3(mk(Q[4]), a, mk(Q[0])));
+        V3 lp = fma3(mk(load4<UNIFORM>(Q, 5)), b, fma3(mk(load4<UNIFORM>(Q, 4)), a, mk(load4<UNIFORM>(Q, 0))));
         return lp - p;
     }
-    const float4 *S = sc.spheres + 3 * idx;
-    float4 s0 = S[0];
+    float4 s0 = load4<UNIFORM>(sc.spheres + 3 * idx, 0);
     V3 dir = mk(s0) - p;
     float dist2 = len2(dir);
     ONB uvw(dir);
@@ -476,13 +516,14 @@ __device__ __forceinline__ V3 light_random(const DScene &sc, uint32_t r, V3 p, R
 }
 
 // Parallelogram::pdf_value (hittable.rs:377-389) / sphere cone pdf
+template <bool UNIFORM>
 __device__ __forceinline__ float light_pdf(const DScene &sc, uint32_t r, V3 p, V3 dir) {
     uint32_t idx = r & RT_REF_INDEX_MASK;
     if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
         const float4 *Q = sc.quads + 6 * idx;
         float t, a, b;
-        if (!hit_quad(Q, p, dir, 0.001f, RT_INF, t, a, b)) return 0.0f;
-        float4 q1 = Q[1];
+        if (!hit_quad<UNIFORM>(Q, p, dir, 0.001f, RT_INF, t, a, b)) return 0.0f;
+        float4 q1 = load4<UNIFORM>(Q, 1);
         float l2 = len2(dir);
         float dist2 = t * t * l2;
         float cosine = fabsf(dot(dir, mk(q1)) / sqrtf(l2));
@@ -490,27 +531,25 @@ __device__ __forceinline__ float light_pdf(const DScene &sc, uint32_t r, V3 p, V
     }
     const float4 *S = sc.spheres + 3 * idx;
     float t;
-    if (!hit_sphere(S, p, dir, 0.f, 0.001f, RT_INF, false, t)) return 0.0f;
-    float4 s0 = S[0];
+    float4 s0 = load4<UNIFORM>(S, 0);
+    if (!hit_sphere(s0, load4<UNIFORM>(S, 1), p, dir, 0.f, 0.001f, RT_INF, false, t)) return 0.0f;
     float dist2 = len2(mk(s0) - p);
     float cos_max = sqrtf(1.0f - s0.w * s0.w / dist2);
     return 1.0f / (2.0f * RT_PI * (1.0f - cos_max));
 }
 
 __device__ __forceinline__ V3 lights_random(const DScene &sc, V3 p, Rng &rng) {
-    uint32_t r;
     if (sc.lights_kind == RT_LIGHTS_LIST) {
         uint32_t i = uint32_t(rng.next() * float(sc.n_lights));
-        r = sc.light_refs[min(i, sc.n_lights - 1)];
-    } else {
-        r = sc.light_refs[0];
+        return light_random<false>(sc, sc.light_refs[min(i, sc.n_lights - 1)], p, rng);
     }
-    return light_random(sc, r, p, rng);
+    return light_random<true>(sc, as_uniform(sc.light_refs)[0], p, rng);
 }
 __device__ __forceinline__ float lights_pdf(const DScene &sc, V3 p, V3 dir) {
-    if (sc.lights_kind != RT_LIGHTS_LIST) return light_pdf(sc, sc.light_refs[0], p, dir);
+    const RT_CONST_AS uint32_t *refs = as_uniform(sc.light_refs);
+    if (sc.lights_kind != RT_LIGHTS_LIST) return light_pdf<true>(sc, refs[0], p, dir);
     float w = 1.0f / float(sc.n_lights), sum = 0.f;
-    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += w * light_pdf(sc, sc.light_refs[i], p, dir);
+    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += w * light_pdf<true>(sc, refs[i], p, dir);
     return sum;
 }
 
@@ -623,8 +662,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Queue q, DCamera cam, uint32
 }
 
 template <bool FLAT>
-__global__ void __launch_bounds__(BLOCK) k_extend(Queue q, DScene sc, uint32_t k0, uint32_t k1, uint32_t flat_first,
-                                                   uint32_t flat_count, uint32_t has_media) {
+__global__ void __launch_bounds__(BLOCK) k_extend(Queue q, DScene sc, uint32_t k0, uint32_t k1, uint32_t has_media) {
     __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
     __shared__ rt_node s_nodes[FLAT ? 1 : LDS_NODES];
     if (!FLAT) { // stage the top of the BVH
@@ -654,7 +692,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend(Queue q, DScene sc, uint32_t k
         }
         Best best;
         if (FLAT)
-            scan_flat(sc, flat_first, flat_count, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
+            scan_flat(sc, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
         else
             traverse<true>(sc, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack + threadIdx.x, s_nodes, best);
         q.hit[s] = make_float4(best.t, bitsf(best.ref), best.u, best.v);
@@ -674,7 +712,7 @@ __device__ __forceinline__ void film_add(const Film &f, uint32_t pixel, V3 c) {
 template <int MODE>
 __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, const Film &film, uint32_t k0,
                                           uint32_t k1, float4 &ra, float4 &rb, float4 &sa, uint2 &sb, float4 h,
-                                          Ctrl *ctrl) {
+                                          uint32_t mat_hint, Ctrl *ctrl) {
     V3 o = mk(ra), d = mk(rb), thr = mk(sa);
     const float time = ra.w;
     const uint32_t pixel = fbits(sa.w);
@@ -698,7 +736,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
     if (kind == RT_KIND_QUAD) {
         const float4 *Q = sc.quads + 6 * idx;
         n = mk(Q[1]);
-        mat_id = fbits(Q[3].w);
+        mat_id = mat_hint != RT_REF_NONE ? mat_hint : fbits(Q[3].w);
     } else if (kind == RT_KIND_SPHERE) {
         const float4 *S = sc.spheres + 3 * idx;
         float4 s0 = S[0], s1 = S[1];
@@ -717,8 +755,10 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
     const rt_material m = sc.mats[mat_id];
     if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
 
+    // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
+    const V3 solid = {m.albedo[0], m.albedo[1], m.albedo[2]};
     if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
-        if (front) film_add(film, pixel, thr * tex_value(sc, m.tex, u, v, p));
+        if (front) film_add(film, pixel, thr * (m.pad ? solid : tex_value(sc, m.tex, u, v, p)));
         return false;
     }
     const uint32_t bounce = sb.y;
@@ -757,7 +797,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
     } else {
         // Lambertian (material.rs:45-63) or Isotropic (material.rs:198-212)
         const bool iso = m.type == RT_MAT_ISOTROPIC;
-        att = tex_value(sc, m.tex, u, v, p);
+        att = m.pad ? solid : tex_value(sc, m.tex, u, v, p);
         float spdf, pdf;
         if (MODE == RT_MODE_REF_EXACT) {
             // Shipped estimator: the material's own sample only feeds scattering_pdf
@@ -833,7 +873,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, DScene sc, DCamera cam
             sa = q.sa[s];
             sb = q.sb[s];
             float4 h = q.hit[s];
-            alive = shade_one<MODE>(sc, cam, film, k0, k1, ra, rb, sa, sb, h, ctrl);
+            alive = shade_one<MODE>(sc, cam, film, k0, k1, ra, rb, sa, sb, h, RT_REF_NONE, ctrl);
         }
         // wave-level stream compaction: ballot + mbcnt prefix
         const unsigned long long mask = __ballot(alive);
@@ -850,11 +890,103 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, DScene sc, DCamera cam
     if (lane == 0) q.count[chunk] = out;
 }
 
+// ------------------------------------------------------------------ persistent path kernel
+// The same pixel x stratum loop with no ray queue: every lane carries one path in registers
+// from its camera ray to its end, and a lane whose path has ended takes the next sample.  A
+// wave owns a range of sample ids, taken `grab` at a time from one global counter, so the
+// counter sees one atomic per `grab` paths.  Dead lanes are refilled once at least
+// `refill_min` of the 64 are idle (the camera ray costs a Philox block; refilling a few lanes
+// at a time would run it at low lane occupancy every bounce).  Because every random number is
+// keyed by (pixel, stratum, bounce), the image does not depend on which lane traces what.
+// Exit: a wave leaves when the counter has passed total_samples and its lanes are idle; both
+// are reached by every wave since a path ends after at most max_depth bounces.
+__device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(x));
+    uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(x >> 32));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+// OCC: waves per SIMD the register allocation is held to (1 = no constraint).
+template <int MODE, bool FLAT, int OCC>
+__global__ void __launch_bounds__(BLOCK, OCC) k_paths(DScene sc, DCamera cam, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
+                                                  uint32_t has_media, uint32_t grab, uint32_t refill_min) {
+    __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
+    __shared__ rt_node s_nodes[FLAT ? 1 : LDS_NODES];
+    if (!FLAT) {
+        const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
+        const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+        float4 *dst = reinterpret_cast<float4 *>(s_nodes);
+        for (uint32_t i = threadIdx.x; i < nn * 4; i += BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long total = ctrl->total_samples;
+    unsigned long long next = 0, end = 0; // sample ids this wave still owns (wave-uniform)
+    unsigned long long n_seg = 0, n_cam = 0;
+    bool exhausted = false;
+    bool alive = false;
+    float4 ra = {}, rb = {}, sa = {};
+    uint2 sb = {};
+    for (;;) {
+        const unsigned long long dead = __ballot(!alive);
+        const uint32_t n_dead = uint32_t(__popcll(dead));
+        if (!exhausted && (n_dead >= refill_min || n_dead == WAVE)) {
+            if (next == end) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(grab));
+                b = wave_first(b);
+                next = b < total ? b : total;
+                end = b + grab < total ? b + grab : total;
+                exhausted = next == end;
+            }
+            const uint32_t prefix =
+                __builtin_amdgcn_mbcnt_hi(uint32_t(dead >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(dead), 0u));
+            const unsigned long long g = next + prefix;
+            if (!alive && g < end) {
+                const uint32_t pixel = uint32_t(g % cam.npix);
+                const uint32_t stratum = cam.stratum_begin + uint32_t(g / cam.npix);
+                V3 o, d;
+                float time;
+                camera_ray(cam, pixel, stratum, k0, k1, o, d, time);
+                ra = make_float4(o.x, o.y, o.z, time);
+                rb = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
+                sa = make_float4(1.f, 1.f, 1.f, bitsf(pixel));
+                sb = make_uint2(stratum, 0u);
+                alive = true;
+            }
+            const unsigned long long took = end - next < n_dead ? end - next : n_dead;
+            next += took;
+            n_cam += took;
+        }
+        const unsigned long long live = __ballot(alive);
+        if (live == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        n_seg += uint32_t(__popcll(live));
+        if (alive) {
+            RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
+            Best best;
+            if (FLAT)
+                scan_flat(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
+            else
+                traverse<true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack + threadIdx.x, s_nodes,
+                               best);
+            alive = shade_one<MODE>(sc, cam, film, k0, k1, ra, rb, sa, sb,
+                                    make_float4(best.t, bitsf(best.ref), best.u, best.v), best.mat, ctrl);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&ctrl->segments, n_seg);
+        atomicAdd(&ctrl->camera_rays, n_cam);
+    }
+}
+
 // ------------------------------------------------------------------ hooks
 template <bool FLAT>
 __global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n, const float *o3, const float *d3,
                                                             const float *time, const uint32_t *origin_ref, float tmin, float tmax,
-                                                            uint32_t flat_first, uint32_t flat_count, int *hit,
+                                                            int *hit,
                                                             int *prim, float *t, float *u, float *v) {
     __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -865,7 +997,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n
     const uint32_t from = origin_ref ? origin_ref[i] : RT_REF_NONE;
     Best best;
     if (FLAT)
-        scan_flat(sc, flat_first, flat_count, o, d, tm, tmin, tmax, from, rc, best);
+        scan_flat(sc, o, d, tm, tmin, tmax, from, rc, best);
     else
         traverse<false>(sc, o, d, tm, tmin, tmax, from, rc, s_stack + threadIdx.x, nullptr, best);
     int pid = -1;

@@ -60,7 +60,7 @@ class DistributedRenderer:
         self.dev.film_bind(self.film.data_ptr(), width, height)
         return self.film
 
-    def render(self, cam, n_strata, rank, world, mode, seed=1, pool_size=0, time_kernels=False, time_every=0, reduce=True):
+    def render(self, cam, n_strata, rank, world, mode, seed=1, reduce=True, **render_args):
         """Renders this rank's strata of every pixel and reduces; returns (film sums, Stats)."""
         if self.film is None or tuple(self.film.shape[1:]) != (cam.image_height, cam.image_width):
             self.bind_film(cam.image_width, cam.image_height)
@@ -68,8 +68,7 @@ class DistributedRenderer:
         begin, end = partition_strata(n_strata, world, rank)
         stats = None
         if end > begin:
-            stats = self.dev.render(cam, mode=mode, seed=seed, stratum_begin=begin, stratum_end=end,
-                                    pool_size=pool_size, time_kernels=time_kernels, time_every=time_every)
+            stats = self.dev.render(cam, mode=mode, seed=seed, stratum_begin=begin, stratum_end=end, **render_args)
         if reduce:
             reduce_film(self.film)
         return self.film, stats
