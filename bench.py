@@ -7,7 +7,8 @@
 
 One step = one full frame of the workload: every rank renders the whole 1200x1200 image for
 its own contiguous share of the 961 (= floor(sqrt(1000))^2, camera.rs:341-342) strata, then the
-fp32 film sums are all-reduced (RCCL).  Total work is fixed, so scaling is "strong"; the value
+fp32 film sums are all-reduced (RCCL).  The default pipeline is the persistent path kernel (one
+launch per step); --wavefront takes the ray-queue pipeline (scan/generate/extend/shade).  Total work is fixed, so scaling is "strong"; the value
 is (segments traced by all ranks) / (slowest rank's time), in Mrays/s.  A segment is one
 closest-hit query issued by the integrator (one world.hit at camera.rs:444).
 Scene and camera are synthetic (generated in code, seeded); inputs are resident in HBM before
@@ -46,10 +47,14 @@ WORKLOADS = {
     "c5": (ra.scenes.stress, dict(n_prims=1_000_000), ra.RT_MODE_BOOK3, "1M random spheres/quads, 3840x2160, 4096 spp"),
 }
 
-# ray-queue bytes one segment moves through each kernel (16-byte records, see rt_kernels.h)
+# ray-queue bytes one segment moves through each wavefront kernel (16-byte records, rt_kernels.h)
 EXTEND_BYTES = 32 + 16           # read origin/time + direction/origin-ref, write the hit record
 SHADE_READ_BYTES = 32 + 24 + 16  # ray, throughput/pixel, stratum/bounce, hit record
 SHADE_WRITE_BYTES = 56           # a surviving ray's records
+FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path deposits radiance
+# algorithmic flops per segment measured by the oracle's counters (flops_per_segment below) on
+# the full workloads; used when the CPU leg is skipped, recomputed when it runs
+FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0}
 
 
 def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads):
@@ -86,7 +91,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (changes the workload)")
     ap.add_argument("--pool", type=int, default=0, help="rays in flight per GPU (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-strata", type=int, default=2, help="strata of the full frame the CPU baseline renders")
+    ap.add_argument("--cpu-strata", type=int, default=6, help="strata of the full frame the CPU baseline renders")
+    ap.add_argument("--wavefront", action="store_true", help="ray-queue pipeline instead of the persistent path kernel")
     args = ap.parse_args()
 
     rank, world, local = rdist.init_from_env()
@@ -114,20 +120,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    extra = dict(wavefront=True, pool_size=args.pool, time_every=8) if args.wavefront else {}
     for _ in range(args.warmup):
-        renderer.render(rcam, n_strata, rank, world, mode, seed=1, pool_size=args.pool)
+        renderer.render(rcam, n_strata, rank, world, mode, seed=1, **extra)
     barrier()
     seg = 0
-    kernel_ms = np.zeros(4)
-    launches = np.zeros(4)
-    timed = np.zeros(4)
+    kernel_ms = np.zeros(5)
+    launches = np.zeros(5)
+    timed = np.zeros(5)
     cam_rays = 0
     t0 = time.perf_counter()
     for step in range(args.steps):
-        # every 8th wavefront iteration is bracketed by HIP events (rotating from step to step):
-        # an event is a barrier packet on the stream, timing all of them costs ~10 %
-        _, st = renderer.render(rcam, n_strata, rank, world, mode, seed=1 + step, pool_size=args.pool, time_kernels=True,
-                                time_every=8)
+        # kernels are bracketed by HIP events on the stream they run on: the one launch of the
+        # persistent kernel, or every 8th wavefront iteration (rotating from step to step; an
+        # event is a barrier packet on the stream, timing all of them costs ~10 %)
+        _, st = renderer.render(rcam, n_strata, rank, world, mode, seed=1 + step, time_kernels=True, **extra)
         if st is not None:
             seg += st.segments
             cam_rays += st.camera_rays
@@ -152,30 +159,33 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = total_seg / elapsed / 1e6
     # dominant kernel of this rank, timed with HIP events on the stream the kernels run on
-    names = ["generate", "extend", "shade", "scan"]
+    names = ["generate", "extend", "shade", "scan", "paths"]
     per_launch_ms = kernel_ms / np.maximum(timed, 1)  # average launch duration, from the timed launches
     k = int(np.argmax(per_launch_ms * launches))
     survive = 1.0 - cam_rays / max(seg, 1)  # every path's last segment does not continue
-    bytes_per_seg = {"extend": EXTEND_BYTES, "shade": SHADE_READ_BYTES + survive * SHADE_WRITE_BYTES}.get(names[k], 56.0)
+    bytes_per_seg = {"extend": EXTEND_BYTES, "shade": SHADE_READ_BYTES + survive * SHADE_WRITE_BYTES,
+                     "paths": FILM_BYTES_PER_PATH * cam_rays / max(seg, 1)}.get(names[k], 56.0)
     avg_launch_ms = per_launch_ms[k]
     seg_per_launch = seg / max(launches[k], 1)
     achieved_gbs = bytes_per_seg * seg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    fps = FLOPS_PER_SEGMENT.get(args.workload)
     out = {
         "metric": "ray segments/s", "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "name": args.workload, "image": [cam.image_width, cam.image_height],
                    "spp": n_strata, "max_depth": cam.max_depth, "estimator": "book3" if mode == ra.RT_MODE_BOOK3 else "ref-exact",
+                   "pipeline": "wavefront" if args.wavefront else "persistent",
                    "parallelism": f"spp-split x{world}, one fp32 film all-reduce per step",
                    "segments_per_step": int(total_seg / args.steps), "segments_per_camera_ray": round(total_seg / max(total_cam, 1), 3)},
         "time_to_1000spp_s": round(ms_per_step * 1e-3 * 1000.0 / n_strata, 4),
-        "roofline": {"bound": "hbm", "kernel": "k_" + names[k], "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                     "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": int(seg_per_launch),
-                     "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]),
-                     "timed_launches": int(timed[k])},
         "kernel_ms_per_step": {n: round(float(per_launch_ms[i] * launches[i]) / args.steps, 3) for i, n in enumerate(names)},
     }
+    # ray-queue / film traffic of the dominant kernel against HBM (the secondary roofline)
+    hbm = {"bound": "hbm", "kernel": "k_" + names[k], "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+           "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": int(seg_per_launch),
+           "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]), "timed_launches": int(timed[k])}
     if world == 1 and not args.no_cpu_baseline:
         cnt, dt, _ = cpu_baseline(scene_fn, kw, mode, args.cpu_strata, threads=1)
         fps = flops_per_segment(cnt)
@@ -186,11 +196,27 @@ def main():
         cnt2, dt2, _ = cpu_baseline(scene_fn, kw, mode, max(args.cpu_strata, 8), threads=nthreads)
         out["cpu_baseline_all_cores"] = {"value": round(cnt2["segments"] / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": nthreads,
                                          "kind": "port", "sample": f"full frame, {max(args.cpu_strata, 8)} strata, OpenMP rows, {dt2:.1f} s"}
-        # secondary roofline: fp32 vector peak, algorithmic flops from the oracle's counters
-        tflops = fps * value * 1e6 / 1e12
-        out["valu"] = {"flops_per_segment": round(fps, 1), "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(tflops / VALU_PEAK_TFLOPS, 5)}
         out["time_to_1000spp_cpu_1core_s"] = round(dt / args.cpu_strata * 1000.0, 1)
+    # The path has no dense contraction and moves almost nothing through HBM: its roofline is
+    # the fp32 vector peak.  achieved = algorithmic flops per segment (reference arithmetic,
+    # FMA = 2, counted by the oracle) x segments per launch / the kernel's launch duration.
+    if fps:
+        kernel_name = "k_" + names[k]
+        tflops = fps * seg_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        if names[k] != "paths":
+            # a segment's arithmetic is spread over the four wavefront kernels: price them together
+            kernel_name = "k_scan+k_generate+k_extend+k_shade"
+            all_ms = float(np.sum(per_launch_ms * launches))
+            tflops = fps * seg / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
+        out["roofline"] = {"bound": "valu", "kernel": kernel_name, "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": None,
+                           "flops_per_segment": round(fps, 1), "segments_per_launch": int(seg_per_launch),
+                           "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]),
+                           "timed_launches": int(timed[k]),
+                           "note": "fp32 vector peak with packed FMA; 78.6 TFLOP/s with scalar v_fma_f32"}
+        out["roofline_hbm"] = hbm
+    else:
+        out["roofline"] = hbm
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

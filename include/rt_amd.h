@@ -168,7 +168,7 @@ typedef struct {
     uint32_t pool_size;                  /* wavefront: rays in flight; 0 = default */
     uint32_t time_every;                 /* wavefront + RT_FLAG_TIME_KERNELS: time every n-th iteration (0 = all) */
     uint32_t refill_min;                 /* persistent: idle lanes of a wave before it takes new samples; 0 = default */
-    uint32_t waves_per_simd;             /* persistent: resident waves per SIMD to launch; 0 = all that fit */
+    uint32_t waves_per_simd;             /* persistent: waves per SIMD to launch; 0 = all that fit (4) */
 } rt_render_params;
 
 typedef struct {

@@ -12,7 +12,8 @@ from pathlib import Path
 # binds to the runtime already in the process.
 import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
 
-_LIB_PATH = Path(__file__).resolve().parent / "librt_amd.so"
+# RT_AMD_LIBRARY names another build of the same library (kernel experiments)
+_LIB_PATH = Path(os.environ.get("RT_AMD_LIBRARY") or Path(__file__).resolve().parent / "librt_amd.so")
 
 u32, u64, i32, f32, f64 = C.c_uint32, C.c_uint64, C.c_int32, C.c_float, C.c_double
 P = C.POINTER

@@ -29,7 +29,9 @@ struct rt_handle {
 
     // scene
     std::vector<void *> scene_allocs;
-    DScene sc{};
+    DScene sc{};           // host copy of the descriptor the kernels read from d_sc
+    DScene *d_sc = nullptr;
+    DCamera *d_cam = nullptr;
     bool have_scene = false;
     bool flat = false;
     uint32_t has_media = 0, n_prims = 0;
@@ -227,6 +229,9 @@ int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCa
     d.sky = c->background_sky != 0;
     *out = d;
     *se = e;
+    // the kernels read the camera from device memory
+    RT_HIP(hipMemcpyAsync(h->d_cam, out, sizeof(DCamera), hipMemcpyHostToDevice, h->stream));
+    RT_HIP(hipStreamSynchronize(h->stream)); // *out is the caller's stack
     return 0;
 }
 
@@ -298,10 +303,10 @@ void drain_timers(rt_handle *h) {
 }
 
 // One launch of the persistent path kernel: as many blocks as the device keeps resident.
-template <int MODE, bool FLAT, int OCC>
+template <int MODE, bool FLAT>
 int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
                  unsigned long long total) {
-    auto kernel = k_paths<MODE, FLAT, OCC>;
+    auto kernel = k_paths<MODE, FLAT>;
     int per_cu = 0, n_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
@@ -315,11 +320,11 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
     unsigned long long blocks_needed = (total + grab * (BLOCK / WAVE) - 1) / (grab * (BLOCK / WAVE));
     unsigned long long blocks = (unsigned long long)per_cu * n_cu;
     if (blocks > blocks_needed) blocks = blocks_needed;
-    uint32_t refill_min = p->refill_min ? p->refill_min : 16u;
+    uint32_t refill_min = p->refill_min ? p->refill_min : 8u;
     if (refill_min > uint32_t(WAVE)) refill_min = WAVE;
     Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
     int e = tm.begin(4);
-    kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), 0, h->stream>>>(h->sc, dc, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
+    kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), 0, h->stream>>>(h->d_sc, h->d_cam, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
                                                                 h->d_ctrl, h->has_media,
                                                                 uint32_t(grab), refill_min);
     tm.end(e);
@@ -332,19 +337,12 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
                       unsigned long long total) {
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
     int rc;
-    const bool exact = p->mode == RT_MODE_REF_EXACT;
-#define RT_PATHS(OCC)                                                                                              \
-    (exact ? (h->flat ? launch_paths<RT_MODE_REF_EXACT, true, OCC>(h, dc, p, film, total)                           \
-                      : launch_paths<RT_MODE_REF_EXACT, false, OCC>(h, dc, p, film, total))                         \
-           : (h->flat ? launch_paths<RT_MODE_BOOK3, true, OCC>(h, dc, p, film, total)                               \
-                      : launch_paths<RT_MODE_BOOK3, false, OCC>(h, dc, p, film, total)))
-    switch (p->waves_per_simd) {
-    case 4: rc = RT_PATHS(4); break;
-    case 5: rc = RT_PATHS(5); break;
-    case 6: rc = RT_PATHS(6); break;
-    default: rc = RT_PATHS(1); break;
-    }
-#undef RT_PATHS
+    if (p->mode == RT_MODE_REF_EXACT)
+        rc = h->flat ? launch_paths<RT_MODE_REF_EXACT, true>(h, dc, p, film, total)
+                     : launch_paths<RT_MODE_REF_EXACT, false>(h, dc, p, film, total);
+    else
+        rc = h->flat ? launch_paths<RT_MODE_BOOK3, true>(h, dc, p, film, total)
+                     : launch_paths<RT_MODE_BOOK3, false>(h, dc, p, film, total);
     if (rc) return rc;
     RT_HIP(hipEventRecord(h->ev_end, h->stream));
     RT_HIP(hipMemcpyAsync(&h->h_ctrl[0], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
@@ -389,6 +387,8 @@ int rt_create(int device_id, rt_handle **out) {
     h = nh;
     hipError_t e = hipStreamCreateWithFlags(&nh->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&nh->d_ctrl, sizeof(Ctrl));
+    if (e == hipSuccess) e = hipMalloc((void **)&nh->d_sc, sizeof(DScene));
+    if (e == hipSuccess) e = hipMalloc((void **)&nh->d_cam, sizeof(DCamera));
     if (e == hipSuccess) e = hipHostMalloc((void **)&nh->h_ctrl, 2 * sizeof(Ctrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreate(&nh->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&nh->ev_end);
@@ -412,6 +412,8 @@ void rt_destroy(rt_handle *h) {
     free_queue(h);
     if (h->film && h->film_owned) (void)hipFree(h->film);
     if (h->d_ctrl) (void)hipFree(h->d_ctrl);
+    if (h->d_sc) (void)hipFree(h->d_sc);
+    if (h->d_cam) (void)hipFree(h->d_cam);
     if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     for (auto &p : h->ev_pool) {
         (void)hipEventDestroy(p.a);
@@ -522,6 +524,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.n_lights = s->n_lights;
     d.lights_kind = s->lights_kind;
     d.n_nodes = s->n_nodes;
+    RT_HIP(hipMemcpyAsync(h->d_sc, &d, sizeof(DScene), hipMemcpyHostToDevice, h->stream));
     RT_HIP(hipStreamSynchronize(h->stream));
     h->sc = d;
     h->have_scene = true;
@@ -670,19 +673,19 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
             k_scan<<<1, 1024, 0, h->stream>>>(h->q, h->d_ctrl);
             tm.end(e);
             e = tm.begin(0);
-            k_generate<<<grid, block, 0, h->stream>>>(h->q, dc, k0, k1);
+            k_generate<<<grid, block, 0, h->stream>>>(h->q, h->d_cam, k0, k1);
             tm.end(e);
             e = tm.begin(1);
             if (h->flat)
-                k_extend<true><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, h->has_media);
+                k_extend<true><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
             else
-                k_extend<false><<<grid, block, 0, h->stream>>>(h->q, h->sc, k0, k1, h->has_media);
+                k_extend<false><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
             tm.end(e);
             e = tm.begin(2);
             if (p->mode == RT_MODE_REF_EXACT)
-                k_shade<RT_MODE_REF_EXACT><<<grid, block, 0, h->stream>>>(h->q, h->sc, dc, film, k0, k1, h->d_ctrl);
+                k_shade<RT_MODE_REF_EXACT><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, h->d_cam, film, k0, k1, h->d_ctrl);
             else
-                k_shade<RT_MODE_BOOK3><<<grid, block, 0, h->stream>>>(h->q, h->sc, dc, film, k0, k1, h->d_ctrl);
+                k_shade<RT_MODE_BOOK3><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, h->d_cam, film, k0, k1, h->d_ctrl);
             tm.end(e);
             h->stats.launches[0]++, h->stats.launches[1]++, h->stats.launches[2]++, h->stats.launches[3]++;
         }
@@ -753,9 +756,9 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (e == hipSuccess) {
         dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
         if (h->flat)
-            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         else
-            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
+            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
                                                                     d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         e = hipGetLastError();
     }
@@ -790,7 +793,7 @@ int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *p
     if (e == hipSuccess) e = hipMemcpyAsync(d_u, pixel, size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_u + n, stratum, size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
-        k_camera_rays<<<(n + 255) / 256, 256, 0, h->stream>>>(dc, uint32_t(p->seed), uint32_t(p->seed >> 32), n, d_u, d_u + n,
+        k_camera_rays<<<(n + 255) / 256, 256, 0, h->stream>>>(h->d_cam, uint32_t(p->seed), uint32_t(p->seed >> 32), n, d_u, d_u + n,
                                                               d_f, d_f + 3 * size_t(n), d_f + 6 * size_t(n));
         e = hipGetLastError();
     }
@@ -816,7 +819,7 @@ int rt_eval_texture(rt_handle *h, uint32_t tex, uint32_t n, const float *uvp, fl
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, size_t(n) * 3 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, uvp, size_t(n) * 20, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
-        k_eval_texture<<<(n + 255) / 256, 256, 0, h->stream>>>(h->sc, tex, n, d_in, d_out);
+        k_eval_texture<<<(n + 255) / 256, 256, 0, h->stream>>>(h->d_sc, tex, n, d_in, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_out, size_t(n) * 12, hipMemcpyDeviceToHost, h->stream);

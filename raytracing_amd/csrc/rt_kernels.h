@@ -24,6 +24,15 @@ constexpr int BLOCK = 256;          // 4 waves = 4 chunks per block
 constexpr int STACK_DEPTH = 32;     // per-lane traversal stack entries (LDS)
 constexpr int LDS_NODES = 128;      // BVH nodes staged per block (8 KiB)
 
+// Read-only scene records through the constant address space: with a wave-uniform address the
+// backend selects scalar loads (s_load_dwordx4..x16), the record lands in SGPRs and feeds the
+// VALU directly -- no vector-memory instruction and no VGPRs per primitive.  Only for arrays
+// nothing writes while a kernel runs.
+#define RT_CONST_AS __attribute__((address_space(4)))
+template <typename T> __device__ __forceinline__ const RT_CONST_AS T *as_uniform(const T *p) {
+    return reinterpret_cast<const RT_CONST_AS T *>(reinterpret_cast<uintptr_t>(p));
+}
+
 struct DScene {
     const rt_node *nodes;
     const uint32_t *refs;
@@ -48,6 +57,13 @@ struct DCamera {
     uint32_t W, H, npix, sqrt_spp, stratum_begin, max_depth, defocus, sky;
     float inv_sqrt;
 };
+
+// Scene and camera live in device memory and are read through the constant address space:
+// fields come in by scalar loads where they are used instead of occupying ~70 SGPRs for the
+// whole kernel (as by-value kernel arguments they did, and spilled).
+using SceneRef = const RT_CONST_AS DScene &;
+using CamRef = const RT_CONST_AS DCamera &;
+__device__ __forceinline__ V3 ldv(const RT_CONST_AS V3 &v) { return V3{v.x, v.y, v.z}; }
 
 struct Ctrl {
     unsigned long long next_sample, total_samples, segments, camera_rays, dropped;
@@ -77,15 +93,6 @@ struct Best {
     float u, v;
     uint32_t mat; // material id when the scan already had the record in hand, else RT_REF_NONE
 };
-
-// Read-only scene records through the constant address space: with a wave-uniform address the
-// backend selects scalar loads (s_load_dwordx4..x16), the record lands in SGPRs and feeds the
-// VALU directly -- no vector-memory instruction and no VGPRs per primitive.  Only for arrays
-// nothing writes while a kernel runs.
-#define RT_CONST_AS __attribute__((address_space(4)))
-template <typename T> __device__ __forceinline__ const RT_CONST_AS T *as_uniform(const T *p) {
-    return reinterpret_cast<const RT_CONST_AS T *>(reinterpret_cast<uintptr_t>(p));
-}
 
 // A 16-byte record element either per lane (vector load) or wave-uniform (scalar load).
 template <bool UNIFORM> __device__ __forceinline__ float4 load4(const float4 *base, size_t i) {
@@ -215,7 +222,7 @@ __device__ __forceinline__ void sphere_uv(V3 n, float u_shift, float &u, float &
 }
 
 // closest boundary hit with t in (tlo, thi) for a ConstantMedium boundary list
-__device__ __forceinline__ bool hit_boundary(const DScene &sc, uint32_t first, uint32_t count, V3 o, V3 d,
+__device__ __forceinline__ bool hit_boundary(SceneRef sc, uint32_t first, uint32_t count, V3 o, V3 d,
                                              float time, float tlo, float thi, float &tout) {
     bool any = false;
     float closest = thi;
@@ -244,7 +251,7 @@ struct RayCtx { // what a medium needs to draw its free-flight distance
 };
 
 // ConstantMedium::hit (hittable.rs:847-886)
-__device__ __forceinline__ bool hit_medium(const DScene &sc, uint32_t idx, V3 o, V3 d, float time, float tlo,
+__device__ __forceinline__ bool hit_medium(SceneRef sc, uint32_t idx, V3 o, V3 d, float time, float tlo,
                                            float thi, const RayCtx &rc, float &tout) {
     rt_medium m = sc.media[idx];
     float t1, t2;
@@ -254,17 +261,17 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, uint32_t idx, V3 o,
     if (t2 > thi) t2 = thi;
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
-    float ray_len = sqrtf(len2(d));
+    float ray_len = fsqrt(len2(d));
     float dist_inside = (t2 - t1) * ray_len;
     float xi = medium_uniform(rc.k0, rc.k1, rc.pixel, rc.sample, rc.bounce, m.prim_id);
     float hit_dist = m.neg_inv_density * logf(xi);
     if (hit_dist > dist_inside) return false;
-    tout = t1 + hit_dist / ray_len;
+    tout = t1 + hit_dist * rcp(ray_len);
     return true;
 }
 
 template <bool UNIFORM = false>
-__device__ __forceinline__ void test_prim(const DScene &sc, uint32_t r, V3 o, V3 d, float time, float tlo,
+__device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, float time, float tlo,
                                           uint32_t origin_ref, const RayCtx &rc, Best &best) {
     uint32_t kind = r >> RT_REF_KIND_SHIFT, idx = r & RT_REF_INDEX_MASK;
     float t, a = 0.f, b = 0.f;
@@ -304,13 +311,13 @@ __device__ __forceinline__ bool hit_box(const float *mn, const float *mx, V3 o, 
 // Closest hit of the world.  `stack` is this lane's column of an LDS array [STACK_DEPTH][BLOCK];
 // `lnodes` the block's LDS copy of nodes[0 .. LDS_NODES).
 template <bool USE_LDS_NODES>
-__device__ __forceinline__ void traverse(const DScene &sc, V3 o, V3 d, float time, float tlo, float thi,
+__device__ __forceinline__ void traverse(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *stack,
                                          const rt_node *lnodes, Best &best) {
     best.t = thi;
     best.ref = best.mat = RT_REF_NONE;
     best.u = best.v = 0.f;
-    V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    V3 inv = {rcp(d.x), rcp(d.y), rcp(d.z)};
     int sp = 0;
     uint32_t cur = sc.root;
     for (;;) {
@@ -377,7 +384,7 @@ __device__ __forceinline__ QuadRec load_quad_rec(const RT_CONST_AS float *p) {
     for (int i = 0; i < 16; ++i) r.f[i] = p[i];
     return r;
 }
-__device__ __forceinline__ void scan_flat(const DScene &sc, V3 o, V3 d, float time, float tlo, float thi,
+__device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
                                           uint32_t origin_ref, const RayCtx &rc, Best &best) {
     best.t = thi;
     best.ref = best.mat = RT_REF_NONE;
@@ -449,7 +456,7 @@ __device__ __forceinline__ float perlin_noise(const float4 *vec, const int *perm
     return accum;
 }
 
-__device__ __forceinline__ V3 tex_value(const DScene &sc, uint32_t id, float u, float v, V3 p) {
+__device__ __forceinline__ V3 tex_value(SceneRef sc, uint32_t id, float u, float v, V3 p) {
     // Checkerboard children are arbitrary textures (texture.rs:39-43): follow the chain
     for (int depth = 0; depth < 16; ++depth) {
         rt_texture t = sc.texs[id];
@@ -494,7 +501,7 @@ __device__ __forceinline__ V3 tex_value(const DScene &sc, uint32_t id, float u, 
 // the visible cap of a sphere
 // UNIFORM: r is the same in every lane, so the light's record comes through scalar loads.
 template <bool UNIFORM>
-__device__ __forceinline__ V3 light_random(const DScene &sc, uint32_t r, V3 p, Rng &rng) {
+__device__ __forceinline__ V3 light_random(SceneRef sc, uint32_t r, V3 p, Rng &rng) {
     uint32_t idx = r & RT_REF_INDEX_MASK;
     if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
         const float4 *Q = sc.quads + 6 * idx;
@@ -509,15 +516,15 @@ __device__ __forceinline__ V3 light_random(const DScene &sc, uint32_t r, V3 p, R
     ONB uvw(dir);
     float r1 = rng.next();
     float r2 = rng.next();
-    float z = 1.0f + r2 * (sqrtf(1.0f - s0.w * s0.w / dist2) - 1.0f);
+    float z = 1.0f + r2 * (fsqrt(1.0f - s0.w * s0.w * rcp(dist2)) - 1.0f);
     float sn = __builtin_amdgcn_sinf(r1), cs = __builtin_amdgcn_cosf(r1);
-    float s = sqrtf(fmaxf(0.f, 1.0f - z * z));
+    float s = fsqrt(fmaxf(0.f, 1.0f - z * z));
     return uvw.transform(V3{cs * s, sn * s, z});
 }
 
 // Parallelogram::pdf_value (hittable.rs:377-389) / sphere cone pdf
 template <bool UNIFORM>
-__device__ __forceinline__ float light_pdf(const DScene &sc, uint32_t r, V3 p, V3 dir) {
+__device__ __forceinline__ float light_pdf(SceneRef sc, uint32_t r, V3 p, V3 dir) {
     uint32_t idx = r & RT_REF_INDEX_MASK;
     if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
         const float4 *Q = sc.quads + 6 * idx;
@@ -526,49 +533,52 @@ __device__ __forceinline__ float light_pdf(const DScene &sc, uint32_t r, V3 p, V
         float4 q1 = load4<UNIFORM>(Q, 1);
         float l2 = len2(dir);
         float dist2 = t * t * l2;
-        float cosine = fabsf(dot(dir, mk(q1)) / sqrtf(l2));
-        return dist2 / (cosine * q1.w);
+        float cosine = fabsf(dot(dir, mk(q1))) * rsq(l2);
+        return dist2 * rcp(cosine * q1.w);
     }
-    const float4 *S = sc.spheres + 3 * idx;
-    float t;
-    float4 s0 = load4<UNIFORM>(S, 0);
-    if (!hit_sphere(s0, load4<UNIFORM>(S, 1), p, dir, 0.f, 0.001f, RT_INF, false, t)) return 0.0f;
-    float dist2 = len2(mk(s0) - p);
-    float cos_max = sqrtf(1.0f - s0.w * s0.w / dist2);
-    return 1.0f / (2.0f * RT_PI * (1.0f - cos_max));
+    // Only hit or miss matters here, for an origin away from the light: the quadratic about the
+    // point of closest approach, disc/a = r^2 - |oc - (h/a) d|^2, without the compensated terms
+    // of hit_sphere.  A root lies in (0.001, inf) iff the far root does.
+    const float4 s0 = load4<UNIFORM>(sc.spheres + 3 * idx, 0);
+    const V3 oc = mk(s0) - p; // pdf_value asks at time 0 (hittable.rs:378)
+    const float a = len2(dir), h = dot(dir, oc), ia = rcp(a);
+    const float disc = fmaf(s0.w, s0.w, -len2(fma3(dir, -(h * ia), oc)));
+    if (!(disc >= 0.0f)) return 0.0f;
+    if (!((h + fsqrt(a * disc)) * ia > 0.001f)) return 0.0f;
+    const float cos_max = fsqrt(1.0f - s0.w * s0.w * rcp(len2(oc)));
+    return rcp(2.0f * RT_PI * (1.0f - cos_max));
 }
 
-__device__ __forceinline__ V3 lights_random(const DScene &sc, V3 p, Rng &rng) {
+__device__ __forceinline__ V3 lights_random(SceneRef sc, V3 p, Rng &rng) {
     if (sc.lights_kind == RT_LIGHTS_LIST) {
         uint32_t i = uint32_t(rng.next() * float(sc.n_lights));
         return light_random<false>(sc, sc.light_refs[min(i, sc.n_lights - 1)], p, rng);
     }
     return light_random<true>(sc, as_uniform(sc.light_refs)[0], p, rng);
 }
-__device__ __forceinline__ float lights_pdf(const DScene &sc, V3 p, V3 dir) {
+__device__ __forceinline__ float lights_pdf(SceneRef sc, V3 p, V3 dir) {
     const RT_CONST_AS uint32_t *refs = as_uniform(sc.light_refs);
     if (sc.lights_kind != RT_LIGHTS_LIST) return light_pdf<true>(sc, refs[0], p, dir);
-    float w = 1.0f / float(sc.n_lights), sum = 0.f;
+    float w = rcp(float(sc.n_lights)), sum = 0.f;
     for (uint32_t i = 0; i < sc.n_lights; ++i) sum += w * light_pdf<true>(sc, refs[i], p, dir);
     return sum;
 }
 
 // ------------------------------------------------------------------ camera (camera.rs:409-430)
-__device__ __forceinline__ void camera_ray(const DCamera &cam, uint32_t pixel, uint32_t stratum, uint32_t k0,
-                                           uint32_t k1, V3 &o, V3 &d, float &time) {
+// rng: the (pixel, stratum) camera stream, begun by the caller
+__device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t stratum, Rng &rng, V3 &o,
+                                           V3 &d, float &time) {
     uint32_t i = pixel % cam.W, j = pixel / cam.W;
     uint32_t si = stratum % cam.sqrt_spp, sj = stratum / cam.sqrt_spp;
-    Rng rng;
-    rng.begin(k0, k1, pixel, stratum, STREAM_CAMERA, 0);
     float ox = ((float(si) + rng.next()) * cam.inv_sqrt) - 0.5f;
     float oy = ((float(sj) + rng.next()) * cam.inv_sqrt) - 0.5f;
     // px_sample - camera_center, accumulated from small terms so the sub-pixel offset
     // survives fp32 (pixel_00 itself sits at scene-scale coordinates)
-    V3 rel = fma3(cam.du, float(i), cam.p00_rel);
-    rel = fma3(cam.dv, float(j), rel);
-    rel = fma3(cam.du, ox, rel);
-    rel = fma3(cam.dv, oy, rel);
-    o = cam.center;
+    V3 rel = fma3(ldv(cam.du), float(i), ldv(cam.p00_rel));
+    rel = fma3(ldv(cam.dv), float(j), rel);
+    rel = fma3(ldv(cam.du), ox, rel);
+    rel = fma3(ldv(cam.dv), oy, rel);
+    o = ldv(cam.center);
     d = rel;
     if (cam.defocus) { // camera.rs:484-488, two_d.rs:183-190
         float px, py;
@@ -577,11 +587,17 @@ __device__ __forceinline__ void camera_ray(const DCamera &cam, uint32_t pixel, u
             py = rng.pm1();
             if (px * px + py * py < 1.0f) break;
         }
-        V3 off = px * cam.disk_u + py * cam.disk_v;
-        o = cam.center + off;
+        V3 off = px * ldv(cam.disk_u) + py * ldv(cam.disk_v);
+        o = ldv(cam.center) + off;
         d = rel - off;
     }
     time = rng.next();
+}
+__device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t stratum, uint32_t k0,
+                                           uint32_t k1, V3 &o, V3 &d, float &time) {
+    Rng rng;
+    rng.begin(k0, k1, pixel, stratum, STREAM_CAMERA, 0);
+    camera_ray(cam, pixel, stratum, rng, o, d, time);
 }
 
 // ------------------------------------------------------------------ kernels
@@ -636,7 +652,8 @@ __global__ void __launch_bounds__(1024) k_scan(Queue q, Ctrl *ctrl) {
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_generate(Queue q, DCamera cam, uint32_t k0, uint32_t k1) {
+__global__ void __launch_bounds__(BLOCK) k_generate(Queue q, const DCamera *camp, uint32_t k0, uint32_t k1) {
+    CamRef cam = *as_uniform(camp);
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t chunk = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x / WAVE);
     if (chunk >= q.n_chunks) return;
@@ -662,7 +679,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Queue q, DCamera cam, uint32
 }
 
 template <bool FLAT>
-__global__ void __launch_bounds__(BLOCK) k_extend(Queue q, DScene sc, uint32_t k0, uint32_t k1, uint32_t has_media) {
+__global__ void __launch_bounds__(BLOCK) k_extend(Queue q, const DScene *scp, uint32_t k0, uint32_t k1, uint32_t has_media) {
+    SceneRef sc = *as_uniform(scp);
     __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
     __shared__ rt_node s_nodes[FLAT ? 1 : LDS_NODES];
     if (!FLAT) { // stage the top of the BVH
@@ -708,17 +726,25 @@ __device__ __forceinline__ void film_add(const Film &f, uint32_t pixel, V3 c) {
     if (c.z != 0.f) atomicAdd(f.b + pixel, c.z);
 }
 
-// camera.rs:451-470 for one path vertex.  Returns true if the path continues.
-template <int MODE>
-__device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, const Film &film, uint32_t k0,
-                                          uint32_t k1, float4 &ra, float4 &rb, float4 &sa, uint2 &sb, float4 h,
-                                          uint32_t mat_hint, Ctrl *ctrl) {
-    V3 o = mk(ra), d = mk(rb), thr = mk(sa);
+// camera.rs:445-453 for one path vertex: what the hit itself contributes.  A miss deposits the
+// background, a light its emission; both end the path (returns false).  Otherwise fills `sf`
+// for the scatter step.
+struct Surface {
+    V3 p, n;
+    float u, v;
+    uint32_t ref;
+    bool front;
+    rt_material m;
+};
+__device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &film, const float4 &ra,
+                                           const float4 &rb, const float4 &sa, float4 h, uint32_t mat_hint,
+                                           Surface &sf) {
+    const V3 o = mk(ra), d = mk(rb), thr = mk(sa);
     const float time = ra.w;
     const uint32_t pixel = fbits(sa.w);
     const uint32_t ref = fbits(h.y);
     if (ref == RT_REF_NONE) { // camera.rs:445-448, 473-482
-        V3 bg = cam.bg;
+        V3 bg = ldv(cam.bg);
         if (cam.sky) {
             float a = 0.5f * (unit(d).y + 1.0f);
             bg = (1.0f - a) * V3{1.f, 1.f, 1.f} + a * V3{0.5f, 0.7f, 1.0f};
@@ -726,8 +752,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
         film_add(film, pixel, thr * bg);
         return false;
     }
-    const float t = h.x;
-    V3 p = fma3(d, t, o);
+    const V3 p = fma3(d, h.x, o);
     const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
     V3 n;
     uint32_t mat_id;
@@ -741,7 +766,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
         const float4 *S = sc.spheres + 3 * idx;
         float4 s0 = S[0], s1 = S[1];
         V3 center = fma3(mk(s1), time, mk(s0));
-        n = (p - center) * (1.0f / s0.w);
+        n = (p - center) * rcp(s0.w);
         mat_id = fbits(s1.w);
         u_shift = S[2].z;
     } else { // ConstantMedium: arbitrary normal, front face (hittable.rs:877-885)
@@ -754,16 +779,24 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
     }
     const rt_material m = sc.mats[mat_id];
     if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
-
-    // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
-    const V3 solid = {m.albedo[0], m.albedo[1], m.albedo[2]};
     if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
-        if (front) film_add(film, pixel, thr * (m.pad ? solid : tex_value(sc, m.tex, u, v, p)));
+        // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
+        if (front) film_add(film, pixel, thr * (m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p)));
         return false;
     }
+    sf.p = p, sf.n = n, sf.u = u, sf.v = v, sf.ref = ref, sf.front = front, sf.m = m;
+    return true;
+}
+
+// camera.rs:455-470: scatter at a surface, choose the next direction, weigh it.  rng is the
+// vertex's shading stream, begun by the caller.  Returns true if the path continues.
+template <int MODE>
+__device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &ra, float4 &rb, float4 &sa,
+                                              uint2 &sb, const Surface &sf, Rng &rng, Ctrl *ctrl) {
+    const V3 d = mk(rb), p = sf.p, n = sf.n;
+    V3 thr = mk(sa);
+    const rt_material &m = sf.m;
     const uint32_t bounce = sb.y;
-    Rng rng;
-    rng.begin(k0, k1, pixel, sb.x, STREAM_SHADE, bounce);
     V3 dir, att;
     float weight = 1.0f;
 
@@ -774,13 +807,13 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
         if (dot(dir, n) < 0.0f) return false;
         att = {m.albedo[0], m.albedo[1], m.albedo[2]};
     } else if (m.type == RT_MAT_DIELECTRIC) { // material.rs:154-182, vec.rs:289-295
-        float ri = front ? 1.0f / m.param : m.param;
+        float ri = sf.front ? rcp(m.param) : m.param;
         V3 ud = unit(d);
         float cos_theta = fminf(-dot(ud, n), 1.0f);
-        float sin_theta = sqrtf(fmaxf(0.f, 1.0f - cos_theta * cos_theta));
+        float sin_theta = fsqrt(fmaxf(0.f, 1.0f - cos_theta * cos_theta));
         bool reflect_it = ri * sin_theta > 1.0f;
         if (!reflect_it) {
-            float r0 = (1.0f - ri) / (1.0f + ri);
+            float r0 = (1.0f - ri) * rcp(1.0f + ri);
             r0 = r0 * r0;
             float x = 1.0f - cos_theta;
             float x2 = x * x;
@@ -790,14 +823,14 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
             dir = ud - n * (2.0f * dot(ud, n));
         } else {
             V3 perp = ri * (ud + cos_theta * n);
-            V3 par = n * (-sqrtf(fabsf(1.0f - len2(perp))));
+            V3 par = n * (-fsqrt(fabsf(1.0f - len2(perp))));
             dir = perp + par;
         }
         att = {1.f, 1.f, 1.f};
     } else {
         // Lambertian (material.rs:45-63) or Isotropic (material.rs:198-212)
         const bool iso = m.type == RT_MAT_ISOTROPIC;
-        att = m.pad ? solid : tex_value(sc, m.tex, u, v, p);
+        att = m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, sf.u, sf.v, p);
         float spdf, pdf;
         if (MODE == RT_MODE_REF_EXACT) {
             // Shipped estimator: the material's own sample only feeds scattering_pdf
@@ -809,7 +842,7 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
                 (void)rng.next(); // r1: azimuth of the discarded cosine sample
                 float r2 = rng.next();
                 // n . unit(onb.transform(cosine sample)) = sqrt(1-r2)
-                spdf = fmaxf(0.f, sqrtf(1.0f - r2) * RT_INV_PI);
+                spdf = fmaxf(0.f, fsqrt(1.0f - r2) * RT_INV_PI);
             }
             dir = lights_random(sc, p, rng);
             pdf = lights_pdf(sc, p, dir);
@@ -825,17 +858,16 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
             } else {
                 float r1 = rng.next();
                 float r2 = rng.next();
-                float sr = sqrtf(r2);
+                float sr = fsqrt(r2);
                 dir = uvw.transform(V3{__builtin_amdgcn_cosf(r1) * sr, __builtin_amdgcn_sinf(r1) * sr,
-                                       sqrtf(1.0f - r2)});
+                                       fsqrt(1.0f - r2)});
             }
-            float inv_len = 1.0f / sqrtf(len2(dir));
-            float cosn = dot(dir, uvw.w) * inv_len;
+            float cosn = dot(dir, uvw.w) * rsq(len2(dir));
             float mpdf = iso ? 0.25f * RT_INV_PI : fmaxf(0.f, cosn * RT_INV_PI);
             spdf = mpdf; // Lambertian::scattering_pdf == CosinePDF::value; Isotropic likewise
             pdf = sc.lights_kind != RT_LIGHTS_NONE ? 0.5f * lights_pdf(sc, p, dir) + 0.5f * mpdf : mpdf;
         }
-        weight = spdf / pdf;
+        weight = spdf * rcp(pdf);
         if (!(pdf > 0.0f) || !(fabsf(weight) <= 3.0e38f)) { // would be inf/NaN radiance
             atomicAdd(&ctrl->dropped, 1ull);
             return false;
@@ -844,16 +876,30 @@ __device__ __forceinline__ bool shade_one(const DScene &sc, const DCamera &cam, 
     }
     if (bounce + 1 >= cam.max_depth) return false; // depth == 0 -> black (camera.rs:439-442)
     thr = thr * att * weight;
-    ra = make_float4(p.x, p.y, p.z, time);
-    rb = make_float4(dir.x, dir.y, dir.z, bitsf(ref));
+    ra = make_float4(p.x, p.y, p.z, ra.w);
+    rb = make_float4(dir.x, dir.y, dir.z, bitsf(sf.ref));
     sa = make_float4(thr.x, thr.y, thr.z, sa.w);
     sb.y = bounce + 1;
     return true;
 }
 
+// camera.rs:451-470 for one path vertex.  Returns true if the path continues.
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_shade(Queue q, DScene sc, DCamera cam, Film film, uint32_t k0,
+__device__ __forceinline__ bool shade_one(SceneRef sc, CamRef cam, const Film &film, uint32_t k0,
+                                          uint32_t k1, float4 &ra, float4 &rb, float4 &sa, uint2 &sb, float4 h,
+                                          uint32_t mat_hint, Ctrl *ctrl) {
+    Surface sf;
+    if (!shade_emit(sc, cam, film, ra, rb, sa, h, mat_hint, sf)) return false;
+    Rng rng;
+    rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
+    return shade_scatter<MODE>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK) k_shade(Queue q, const DScene *scp, const DCamera *camp, Film film, uint32_t k0,
                                                   uint32_t k1, Ctrl *ctrl) {
+    SceneRef sc = *as_uniform(scp);
+    CamRef cam = *as_uniform(camp);
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t chunk = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x / WAVE);
     if (chunk >= q.n_chunks) return;
@@ -906,10 +952,13 @@ __device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-// OCC: waves per SIMD the register allocation is held to (1 = no constraint).
-template <int MODE, bool FLAT, int OCC>
-__global__ void __launch_bounds__(BLOCK, OCC) k_paths(DScene sc, DCamera cam, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
+// Registers are held to 128 per lane (4 waves per SIMD): measured faster than 3 waves with no
+// spills or 5 with more, on every workload.
+template <int MODE, bool FLAT>
+__global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
                                                   uint32_t has_media, uint32_t grab, uint32_t refill_min) {
+    SceneRef sc = *as_uniform(scp);
+    CamRef cam = *as_uniform(camp);
     __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
     __shared__ rt_node s_nodes[FLAT ? 1 : LDS_NODES];
     if (!FLAT) {
@@ -922,48 +971,19 @@ __global__ void __launch_bounds__(BLOCK, OCC) k_paths(DScene sc, DCamera cam, Fi
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const unsigned long long total = ctrl->total_samples;
     unsigned long long next = 0, end = 0; // sample ids this wave still owns (wave-uniform)
+    uint32_t next_pixel = 0, next_stratum = 0; // (pixel, stratum) of sample id `next`
     unsigned long long n_seg = 0, n_cam = 0;
     bool exhausted = false;
-    bool alive = false;
+    bool alive = false; // this lane holds a ray to trace
     float4 ra = {}, rb = {}, sa = {};
     uint2 sb = {};
     for (;;) {
-        const unsigned long long dead = __ballot(!alive);
-        const uint32_t n_dead = uint32_t(__popcll(dead));
-        if (!exhausted && (n_dead >= refill_min || n_dead == WAVE)) {
-            if (next == end) {
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(grab));
-                b = wave_first(b);
-                next = b < total ? b : total;
-                end = b + grab < total ? b + grab : total;
-                exhausted = next == end;
-            }
-            const uint32_t prefix =
-                __builtin_amdgcn_mbcnt_hi(uint32_t(dead >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(dead), 0u));
-            const unsigned long long g = next + prefix;
-            if (!alive && g < end) {
-                const uint32_t pixel = uint32_t(g % cam.npix);
-                const uint32_t stratum = cam.stratum_begin + uint32_t(g / cam.npix);
-                V3 o, d;
-                float time;
-                camera_ray(cam, pixel, stratum, k0, k1, o, d, time);
-                ra = make_float4(o.x, o.y, o.z, time);
-                rb = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
-                sa = make_float4(1.f, 1.f, 1.f, bitsf(pixel));
-                sb = make_uint2(stratum, 0u);
-                alive = true;
-            }
-            const unsigned long long took = end - next < n_dead ? end - next : n_dead;
-            next += took;
-            n_cam += took;
-        }
+        // 1. closest hit, then what the hit itself contributes (background, emission)
         const unsigned long long live = __ballot(alive);
-        if (live == 0) {
-            if (exhausted) break;
-            continue;
-        }
+        if (live == 0 && exhausted) break;
         n_seg += uint32_t(__popcll(live));
+        bool scatter = false; // the path goes on from a surface
+        Surface sf;
         if (alive) {
             RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
             Best best;
@@ -972,8 +992,56 @@ __global__ void __launch_bounds__(BLOCK, OCC) k_paths(DScene sc, DCamera cam, Fi
             else
                 traverse<true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack + threadIdx.x, s_nodes,
                                best);
-            alive = shade_one<MODE>(sc, cam, film, k0, k1, ra, rb, sa, sb,
-                                    make_float4(best.t, bitsf(best.ref), best.u, best.v), best.mat, ctrl);
+            scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
+                                 best.mat, sf);
+        }
+        // 2. idle lanes take new samples
+        bool fresh = false;
+        const unsigned long long idle = __ballot(!scatter);
+        const uint32_t n_idle = uint32_t(__popcll(idle));
+        if (!exhausted && (n_idle >= refill_min || n_idle == WAVE)) {
+            if (next == end) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(grab));
+                b = wave_first(b);
+                next = b < total ? b : total;
+                end = b + grab < total ? b + grab : total;
+                exhausted = next == end;
+                next_pixel = uint32_t(next % cam.npix); // the only 64-bit divisions: once per grab
+                next_stratum = cam.stratum_begin + uint32_t(next / cam.npix);
+            }
+            const uint32_t prefix =
+                __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+            const unsigned long long g = next + prefix;
+            if (!scatter && g < end) {
+                uint32_t px = next_pixel + prefix, st = next_stratum;
+                while (px >= cam.npix) px -= cam.npix, ++st;
+                sa.w = bitsf(px);
+                sb = make_uint2(st, 0u);
+                fresh = true;
+            }
+            const uint32_t took = uint32_t(end - next < n_idle ? end - next : n_idle);
+            next += took;
+            n_cam += took;
+            next_pixel += took;
+            while (next_pixel >= cam.npix) next_pixel -= cam.npix, ++next_stratum;
+        }
+        // 3. one Philox block for every lane: the camera stream of a new sample or the
+        //    shading stream of this vertex
+        Rng rng;
+        rng.begin(k0, k1, fbits(sa.w), sb.x, fresh ? STREAM_CAMERA : STREAM_SHADE, sb.y);
+        if (fresh) {
+            V3 o, d;
+            float time;
+            camera_ray(cam, fbits(sa.w), sb.x, rng, o, d, time);
+            ra = make_float4(o.x, o.y, o.z, time);
+            rb = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
+            sa = make_float4(1.f, 1.f, 1.f, sa.w);
+            alive = true;
+        } else if (scatter) {
+            alive = shade_scatter<MODE>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+        } else {
+            alive = false;
         }
     }
     if (lane == 0) {
@@ -984,10 +1052,11 @@ __global__ void __launch_bounds__(BLOCK, OCC) k_paths(DScene sc, DCamera cam, Fi
 
 // ------------------------------------------------------------------ hooks
 template <bool FLAT>
-__global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n, const float *o3, const float *d3,
+__global__ void __launch_bounds__(BLOCK) k_intersect_batch(const DScene *scp, uint32_t n, const float *o3, const float *d3,
                                                             const float *time, const uint32_t *origin_ref, float tmin, float tmax,
                                                             int *hit,
                                                             int *prim, float *t, float *u, float *v) {
+    SceneRef sc = *as_uniform(scp);
     __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -1025,8 +1094,9 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(DScene sc, uint32_t n
     v[i] = vv;
 }
 
-__global__ void k_camera_rays(DCamera cam, uint32_t k0, uint32_t k1, uint32_t n, const uint32_t *pixel,
+__global__ void k_camera_rays(const DCamera *camp, uint32_t k0, uint32_t k1, uint32_t n, const uint32_t *pixel,
                               const uint32_t *stratum, float *o3, float *d3, float *time) {
+    CamRef cam = *as_uniform(camp);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     V3 o, d;
@@ -1037,7 +1107,8 @@ __global__ void k_camera_rays(DCamera cam, uint32_t k0, uint32_t k1, uint32_t n,
     time[i] = tm;
 }
 
-__global__ void k_eval_texture(DScene sc, uint32_t tex, uint32_t n, const float *uvp, float *rgb) {
+__global__ void k_eval_texture(const DScene *scp, uint32_t tex, uint32_t n, const float *uvp, float *rgb) {
+    SceneRef sc = *as_uniform(scp);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     V3 c = tex_value(sc, tex, uvp[5 * i], uvp[5 * i + 1], V3{uvp[5 * i + 2], uvp[5 * i + 3], uvp[5 * i + 4]});

@@ -29,7 +29,11 @@ __device__ __forceinline__ V3 fma3(V3 a, float s, V3 b) { // a*s + b
     return {fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z)};
 }
 __device__ __forceinline__ float len2(V3 a) { return dot(a, a); }
-__device__ __forceinline__ V3 unit(V3 a) { return a * (1.0f / sqrtf(len2(a))); }
+// single-instruction reciprocal, reciprocal square root and square root (1 ulp)
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ V3 unit(V3 a) { return a * rsq(len2(a)); }
 
 // ------------------------------------------------------------------ Philox4x32-10
 __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -55,6 +59,8 @@ __device__ __forceinline__ float u24(uint32_t u) { return float(u >> 8) * (1.0f 
 
 // Sequential uniforms for one (pixel, stratum, bounce, stream): counter = (pixel, stratum,
 // bounce<<8 | stream, block); four 24-bit uniforms per Philox block, consumed in order.
+// begin() computes block 0 at once: callers start the stream where every lane is still active
+// and then branch, so the ten rounds run once at full occupancy instead of once per branch.
 struct Rng {
     uint32_t k0, k1, pixel, sample, c2, block;
     uint32_t b[4];
@@ -63,8 +69,9 @@ struct Rng {
                                           uint32_t stream, uint32_t bounce) {
         k0 = key0, k1 = key1, pixel = px, sample = smp;
         c2 = (bounce << 8) | stream;
-        block = 0;
-        pos = 4;
+        philox4x32_10(pixel, sample, c2, 0u, k0, k1, b);
+        block = 1;
+        pos = 0;
     }
     __device__ __forceinline__ float next() {
         if (pos == 4) {

@@ -161,7 +161,9 @@ def test_render_same_stream_pixelwise(device, name, med, frac, wavefront):
     assert st.camera_rays == cnt["camera_rays"]
     # the device stops a path whose weight is exactly 0; the oracle traces it on (and counts it)
     want = cnt["segments"] - cnt["zero_weight_segments"]
-    assert abs(st.segments - want) <= 2e-3 * want + 5, (st.segments, want)
+    # a fork changes a path's length by up to max_depth segments: the totals differ by noise
+    # (measured sigma ~0.15 % on the mirror/glass scenes at this size), not by a bias
+    assert abs(st.segments - want) <= 5e-3 * want + 5, (st.segments, want)
 
 
 def test_render_matches_committed_golden_images(device):

@@ -22,8 +22,8 @@ dev.upload(sb)
 rc = cam.build()
 dev.film_resize(cam.image_width, cam.image_height)
 variants = [dict(wavefront=True)]
-for wps in (0, 4, 5, 6):
-    for rm in (1, 8, 16):
+for wps in (4,):
+    for rm in (8,):
         variants.append(dict(refill_min=rm, waves_per_simd=wps))
 dev.render(rc, mode=mode, seed=1)
 for v in variants:
