@@ -55,6 +55,10 @@ FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path dep
 # algorithmic flops per segment measured by the oracle's counters (flops_per_segment below) on
 # the full workloads; used when the CPU leg is skipped, recomputed when it runs
 FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0}
+# HBM-side bytes per segment of the persistent kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
+# WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments;
+# profiles/r1b_pmc_c3_spp64_persistent.txt).  Not collected live: counters need their own runs.
+PMC_BYTES_PER_SEGMENT = {"c3": (2 * 2972 + 4900085) * 1024 / 861.4e6}
 
 
 def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads):
@@ -209,7 +213,10 @@ def main():
             all_ms = float(np.sum(per_launch_ms * launches))
             tflops = fps * seg / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
         out["roofline"] = {"bound": "valu", "kernel": kernel_name, "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 5), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 5),
+                           "traffic": (round(PMC_BYTES_PER_SEGMENT[args.workload] * seg_per_launch)
+                                       if names[k] == "paths" and args.workload in PMC_BYTES_PER_SEGMENT and not args.spp else None),
+                           "traffic_unit": "bytes per launch, HBM side, PMC bytes/segment x segments of this launch",
                            "flops_per_segment": round(fps, 1), "segments_per_launch": int(seg_per_launch),
                            "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]),
                            "timed_launches": int(timed[k]),
