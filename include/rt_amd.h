@@ -210,6 +210,15 @@ int rt_film_bind(rt_handle *h, void *device_ptr, uint32_t width, uint32_t height
 int rt_film_device_ptr(rt_handle *h, void **device_ptr, uint64_t *n_floats);
 /* rgb: width*height*3 interleaved, each = sum * scale (scale = 1/spp gives camera.rs:397) */
 int rt_film_download(rt_handle *h, float *rgb, float scale);
+/* Restores film sums saved by rt_film_download(h, rgb, 1.0f) (interleaved, width*height*3):
+ * with the stratum range of rt_render_params this resumes an interrupted render. */
+int rt_film_upload(rt_handle *h, const float *rgb, uint32_t width, uint32_t height);
+/* Output stage on the device: rgb8 (width*height*3 bytes, host) = the reference's 8-bit rule on
+ * sum * scale -- `pixel_color * px_sample_scale` (camera.rs:397), then as_gamma_corrected
+ * (gamma != 0; PpmWriter, export.rs:35-36, color.rs:131-137, 209-215) or linear (PngWriter,
+ * export.rs:80), then as_rgb_ints: clamp to [0,1], * 255, truncate (color.rs:148-155).
+ * Evaluated in f64 on the fp32 sums. */
+int rt_film_quantize(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma);
 int rt_get_stats(rt_handle *h, rt_stats *out);
 
 /* Parity hook: closest hit of the uploaded world for n host rays (o,d: n*3; time: n or NULL).
@@ -304,6 +313,12 @@ double rth_interval_clamp(double a, double b, double x);
  * PNG writes linear values, PPM applies gamma 2, both truncate (color.rs:148-155). */
 int rth_write_png(const char *path, uint32_t w, uint32_t h, const float *rgb);
 int rth_write_ppm(const char *path, uint32_t w, uint32_t h, const float *rgb);
+/* The same files from bytes already quantised (rt_film_quantize with gamma 0 / 1). */
+int rth_write_png_rgb8(const char *path, uint32_t w, uint32_t h, const uint8_t *rgb8);
+int rth_write_ppm_rgb8(const char *path, uint32_t w, uint32_t h, const uint8_t *rgb8);
+/* 8-bit RGB PNG -> bytes (the loader behind ImageTexture, texture.rs:95-122); rgb8 may be NULL
+ * to query the size. */
+int rth_read_png_rgb8(const char *path, uint32_t *w, uint32_t *h, uint8_t *rgb8, uint64_t capacity);
 
 #ifdef __cplusplus
 }

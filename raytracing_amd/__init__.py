@@ -7,4 +7,4 @@ This package only binds it; importing fails if the library has not been built.
 from ._ffi import RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT, RT_MODE_BOOK3, RT_MODE_REF_EXACT  # noqa: F401
 from .api import (CameraSettings, Device, RtError, SceneBuilder, Stats, device_count,  # noqa: F401
                   SHAPE_DISC, SHAPE_PARALLELOGRAM, SHAPE_TRIANGLE)
-from . import scenes  # noqa: F401
+from . import imageio, progressive, scenes  # noqa: F401

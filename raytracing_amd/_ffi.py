@@ -103,6 +103,8 @@ SIGNATURES = {
     "rt_film_bind": (C.c_int, [_vp, _vp, u32, u32]),
     "rt_film_device_ptr": (C.c_int, [_vp, P(_vp), P(u64)]),
     "rt_film_download": (C.c_int, [_vp, P(f32), f32]),
+    "rt_film_upload": (C.c_int, [_vp, P(f32), u32, u32]),
+    "rt_film_quantize": (C.c_int, [_vp, P(C.c_uint8), f64, u32]),
     "rt_get_stats": (C.c_int, [_vp, P(RtStats)]),
     "rt_intersect_batch": (C.c_int, [_vp, u32, P(f32), P(f32), P(f32), P(i32), f32, f32, P(i32), P(i32), P(f32), P(f32), P(f32)]),
     "rt_camera_rays": (C.c_int, [_vp, P(RtCamera), P(RtRenderParams), u32, P(u32), P(u32), P(f32), P(f32), P(f32)]),
@@ -150,6 +152,9 @@ SIGNATURES = {
     "rth_interval_clamp": (f64, [f64, f64, f64]),
     "rth_write_png": (C.c_int, [C.c_char_p, u32, u32, P(f32)]),
     "rth_write_ppm": (C.c_int, [C.c_char_p, u32, u32, P(f32)]),
+    "rth_write_png_rgb8": (C.c_int, [C.c_char_p, u32, u32, P(C.c_uint8)]),
+    "rth_write_ppm_rgb8": (C.c_int, [C.c_char_p, u32, u32, P(C.c_uint8)]),
+    "rth_read_png_rgb8": (C.c_int, [C.c_char_p, P(u32), P(u32), P(C.c_uint8), u64]),
 }
 
 

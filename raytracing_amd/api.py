@@ -316,6 +316,23 @@ class Device:
                     "rt_film_download")
         return out
 
+    def film_rgb8(self, scale, gamma=False):
+        """(H, W, 3) uint8: the reference's 8-bit rule applied to sums * scale on the device
+        (gamma=True is what PpmWriter writes, False what PngWriter writes)."""
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        self._check(self.lib.rt_film_quantize(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(scale),
+                                              1 if gamma else 0), "rt_film_quantize")
+        return out
+
+    def film_upload(self, sums):
+        """Restores film sums: (H, W, 3) float32 as returned by film(1.0)."""
+        a = np.ascontiguousarray(sums, dtype=np.float32)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("film sums must have shape (H, W, 3)")
+        self._check(self.lib.rt_film_upload(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0]),
+                    "rt_film_upload")
+        self.width, self.height = a.shape[1], a.shape[0]
+
     def film_device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self.lib.rt_film_device_ptr(self.h, C.byref(p), C.byref(n)), "rt_film_device_ptr")

@@ -312,12 +312,10 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
     if (p->waves_per_simd && int(p->waves_per_simd) < per_cu) per_cu = int(p->waves_per_simd); // a block is one wave per SIMD
-    unsigned long long waves = (unsigned long long)per_cu * n_cu * (BLOCK / WAVE);
-    // samples a wave takes from the global counter at a time: large enough that the counter is
-    // idle, small enough that the last waves to finish hold little work
-    unsigned long long grab = total / (waves * 8ull);
-    grab = grab > 1024 ? 1024 : (grab < 64 ? 64 : (grab & ~63ull));
-    unsigned long long blocks_needed = (total + grab * (BLOCK / WAVE) - 1) / (grab * (BLOCK / WAVE));
+    // most samples a wave takes from the global counter at a time (the kernel takes fewer as the
+    // work runs out); 1024 keeps the counter idle: one atomic per 1024 paths
+    const unsigned long long grab = 1024;
+    unsigned long long blocks_needed = (total + WAVE * (BLOCK / WAVE) - 1) / (WAVE * (BLOCK / WAVE));
     unsigned long long blocks = (unsigned long long)per_cu * n_cu;
     if (blocks > blocks_needed) blocks = blocks_needed;
     uint32_t refill_min = p->refill_min ? p->refill_min : 8u;
@@ -602,6 +600,46 @@ int rt_film_download(rt_handle *h, float *rgb, float scale) {
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(h, std::string("rt_film_download: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rt_film_upload(rt_handle *h, const float *rgb, uint32_t w, uint32_t hgt) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!rgb || w == 0 || hgt == 0) return fail(h, "rt_film_upload: null source or empty film");
+    if (h->film && !h->film_owned && (w != h->film_w || hgt != h->film_h))
+        return fail(h, "rt_film_upload: size differs from the bound film");
+    if (ensure_film(h, w, hgt)) return -1;
+    const uint32_t npix = w * hgt;
+    float *tmp = nullptr;
+    RT_HIP(hipMalloc((void **)&tmp, size_t(npix) * 3 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(tmp, rgb, size_t(npix) * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        k_film_unpack<<<(npix + 255) / 256, 256, 0, h->stream>>>(tmp, npix, h->film, h->film + npix, h->film + 2 * size_t(npix));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(h, std::string("rt_film_upload: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int rt_film_quantize(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!h->film) return fail(h, "rt_film_quantize: no film");
+    if (!rgb8) return fail(h, "rt_film_quantize: null destination");
+    const uint32_t npix = h->film_w * h->film_h;
+    const uint32_t groups = (npix + 3u) / 4u;
+    uint32_t *tmp = nullptr;
+    RT_HIP(hipMalloc((void **)&tmp, size_t(groups) * 12));
+    k_film_quantize<<<(groups + 255) / 256, 256, 0, h->stream>>>(h->film, h->film + npix, h->film + 2 * size_t(npix), npix, scale,
+                                                                gamma, tmp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb8, tmp, size_t(npix) * 3, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(h, std::string("rt_film_quantize: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -939,8 +939,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, const DScene *scp, con
 // ------------------------------------------------------------------ persistent path kernel
 // The same pixel x stratum loop with no ray queue: every lane carries one path in registers
 // from its camera ray to its end, and a lane whose path has ended takes the next sample.  A
-// wave owns a range of sample ids, taken `grab` at a time from one global counter, so the
-// counter sees one atomic per `grab` paths.  Dead lanes are refilled once at least
+// wave owns a range of sample ids, taken up to `grab` at a time from one global counter, so the
+// counter sees about one atomic per `grab` paths.  Dead lanes are refilled once at least
 // `refill_min` of the 64 are idle (the camera ray costs a Philox block; refilling a few lanes
 // at a time would run it at low lane occupancy every bounce).  Because every random number is
 // keyed by (pixel, stratum, bounce), the image does not depend on which lane traces what.
@@ -971,6 +971,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const unsigned long long total = ctrl->total_samples;
     unsigned long long next = 0, end = 0; // sample ids this wave still owns (wave-uniform)
+    unsigned long long seen = 0;          // counter value at this wave's last request
+    const float inv_share = 1.0f / (4.0f * float(gridDim.x * (BLOCK / WAVE))); // a quarter of an even share
     uint32_t next_pixel = 0, next_stratum = 0; // (pixel, stratum) of sample id `next`
     unsigned long long n_seg = 0, n_cam = 0;
     bool exhausted = false;
@@ -1001,11 +1003,17 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         const uint32_t n_idle = uint32_t(__popcll(idle));
         if (!exhausted && (n_idle >= refill_min || n_idle == WAVE)) {
             if (next == end) {
+                // guided self-scheduling: ranges shrink with the work that is left (estimated
+                // from the counter value this wave saw last), so the last waves finish together
+                const float left = float(total > seen ? total - seen : 0ull);
+                uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
+                take = take < uint32_t(WAVE) ? uint32_t(WAVE) : (take & ~uint32_t(WAVE - 1));
                 unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(grab));
+                if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(take));
                 b = wave_first(b);
+                seen = b;
                 next = b < total ? b : total;
-                end = b + grab < total ? b + grab : total;
+                end = b + take < total ? b + take : total;
                 exhausted = next == end;
                 next_pixel = uint32_t(next % cam.npix); // the only 64-bit divisions: once per grab
                 next_stratum = cam.stratum_begin + uint32_t(next / cam.npix);
@@ -1130,6 +1138,45 @@ __global__ void k_film_pack(const float *r, const float *g, const float *b, uint
     rgb[3 * i] = r[i] * scale;
     rgb[3 * i + 1] = g[i] * scale;
     rgb[3 * i + 2] = b[i] * scale;
+}
+
+// interleaved rgb sums -> film planes (restoring a saved film)
+__global__ void k_film_unpack(const float *rgb, uint32_t npix, float *r, float *g, float *b) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    r[i] = rgb[3 * i];
+    g[i] = rgb[3 * i + 1];
+    b[i] = rgb[3 * i + 2];
+}
+
+// Output stage: film sums -> 8-bit RGB with the reference's rule: value = sum * scale
+// (camera.rs:397), optional gamma 2 = sqrt, 0 for values <= 0 (color.rs:209-215), clamp to
+// [0, 1], * 255, truncate (color.rs:148-155; NaN -> 0 as a Rust `as u8` cast does).  Evaluated
+// in f64 like the reference, so the bytes equal the reference rule applied to the same sums.
+// One thread packs four pixels = 12 bytes = three dword stores.
+__device__ __forceinline__ uint32_t quantize_channel(float sum, double scale, bool gamma) {
+    double c = double(sum) * scale;
+    if (gamma) c = c > 0.0 ? sqrt(c) : 0.0;
+    c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c); // Interval::clamp (interval.rs:151-153); NaN passes through
+    c *= 255.0;
+    return c >= 0.0 ? uint32_t(c) : 0u;       // NaN fails the comparison -> 0
+}
+__global__ void k_film_quantize(const float *r, const float *g, const float *b, uint32_t npix, double scale,
+                                uint32_t gamma, uint32_t *out /* ceil(npix/4) * 3 dwords */) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; // group of four pixels
+    if (q * 4u >= npix) return;
+    uint32_t bytes[12];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = q * 4u + k;
+        const bool in = i < npix;
+        bytes[3 * k] = in ? quantize_channel(r[i], scale, gamma != 0) : 0u;
+        bytes[3 * k + 1] = in ? quantize_channel(g[i], scale, gamma != 0) : 0u;
+        bytes[3 * k + 2] = in ? quantize_channel(b[i], scale, gamma != 0) : 0u;
+    }
+#pragma unroll
+    for (uint32_t w = 0; w < 3; ++w)
+        out[q * 3u + w] = bytes[4 * w] | (bytes[4 * w + 1] << 8) | (bytes[4 * w + 2] << 16) | (bytes[4 * w + 3] << 24);
 }
 
 } // namespace rt

@@ -309,6 +309,38 @@ int rth_write_png(const char *path, uint32_t w, uint32_t h, const float *rgb) {
         return -1;
     }
 }
+int rth_write_png_rgb8(const char *path, uint32_t w, uint32_t h, const uint8_t *rgb8) {
+    try {
+        write_png_rgb8(path, w, h, rgb8);
+        return 0;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+int rth_write_ppm_rgb8(const char *path, uint32_t w, uint32_t h, const uint8_t *rgb8) {
+    try {
+        write_ppm_rgb8(path, w, h, rgb8);
+        return 0;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
+int rth_read_png_rgb8(const char *path, uint32_t *w, uint32_t *h, uint8_t *rgb8, uint64_t capacity) {
+    try {
+        std::vector<uint8_t> px;
+        uint32_t ww = 0, hh = 0;
+        read_png_rgb8(path, px, ww, hh);
+        if (w) *w = ww;
+        if (h) *h = hh;
+        if (rgb8) {
+            if (capacity < px.size()) return -2;
+            std::memcpy(rgb8, px.data(), px.size());
+        }
+        return 0;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
 int rth_write_ppm(const char *path, uint32_t w, uint32_t h, const float *rgb) {
     try {
         write_ppm(path, w, h, rgb);

@@ -44,12 +44,15 @@ uint8_t paeth(int a, int b, int c) {
 
 // PngWriter::write (export.rs:77-86): linear values, 8-bit RGB
 void write_png(const std::string &path, uint32_t w, uint32_t h, const float *rgb) {
-    std::vector<uint8_t> px = quantize(w, h, rgb, false);
+    write_png_rgb8(path, w, h, quantize(w, h, rgb, false).data());
+}
+
+void write_png_rgb8(const std::string &path, uint32_t w, uint32_t h, const uint8_t *rgb8) {
     std::vector<uint8_t> raw;
     raw.reserve((size_t(w) * 3 + 1) * h);
     for (uint32_t y = 0; y < h; ++y) {
         raw.push_back(0); // filter: none
-        raw.insert(raw.end(), px.begin() + size_t(y) * w * 3, px.begin() + size_t(y + 1) * w * 3);
+        raw.insert(raw.end(), rgb8 + size_t(y) * w * 3, rgb8 + size_t(y + 1) * w * 3);
     }
     uLongf clen = compressBound(uLong(raw.size()));
     std::vector<uint8_t> comp(clen);
@@ -71,7 +74,10 @@ void write_png(const std::string &path, uint32_t w, uint32_t h, const float *rgb
 
 // PpmWriter (export.rs:28-41): P3, gamma 2
 void write_ppm(const std::string &path, uint32_t w, uint32_t h, const float *rgb) {
-    std::vector<uint8_t> px = quantize(w, h, rgb, true);
+    write_ppm_rgb8(path, w, h, quantize(w, h, rgb, true).data());
+}
+
+void write_ppm_rgb8(const std::string &path, uint32_t w, uint32_t h, const uint8_t *px) {
     FILE *f = std::fopen(path.c_str(), "w");
     if (!f) throw Error("write_ppm: cannot open " + path);
     std::fprintf(f, "P3\n%u %u\n255\n", w, h);

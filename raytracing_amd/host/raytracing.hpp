@@ -333,6 +333,8 @@ class ConfigModel {
 // ------------------------------------------------------------------ image writers (export.rs)
 void write_png(const std::string &path, uint32_t w, uint32_t h, const float *rgb); // linear, truncating
 void write_ppm(const std::string &path, uint32_t w, uint32_t h, const float *rgb); // gamma 2, truncating
+void write_png_rgb8(const std::string &path, uint32_t w, uint32_t h, const uint8_t *rgb8); // bytes as given
+void write_ppm_rgb8(const std::string &path, uint32_t w, uint32_t h, const uint8_t *rgb8);
 void read_png_rgb8(const std::string &path, std::vector<uint8_t> &rgb, uint32_t &w, uint32_t &h);
 
 } // namespace raytracing

@@ -384,3 +384,62 @@ def test_film_bound_to_a_torch_tensor_and_stream(device):
         device.film_bind(want.ctypes.data, 64, 64)
     device.set_stream(None)
     device.film_resize(64, 64)
+
+
+def test_output_stage_bytes_equal_the_reference_rule(device):
+    """rt_film_quantize against the oracle's Color::as_gamma_corrected / as_rgb_ints
+    (color.rs:130-155) on the same fp32 sums: bit-exact, including the values where the
+    rule is delicate (k/255 boundaries, negatives, > 1, inf, NaN)."""
+    rng = np.random.default_rng(11)
+    h, w = 37, 53  # not a multiple of the 4-pixel packing
+    sums = (rng.random((h, w, 3)) * 40.0).astype(np.float32)
+    flat = sums.reshape(-1)
+    spp = 16
+    k = np.arange(256, dtype=np.float64)
+    edge = np.concatenate([k / 255.0 * spp, np.nextafter(k / 255.0 * spp, 1e9), np.nextafter(k / 255.0 * spp, -1e9),
+                           (k / 255.0) ** 2 * spp]).astype(np.float32)
+    flat[:edge.size] = edge
+    flat[edge.size:edge.size + 8] = [-1.0, -0.0, 0.0, np.inf, -np.inf, np.nan, 1e30, 17.0]
+    device.film_upload(sums)
+    assert np.array_equal(device.film(1.0), sums, equal_nan=True)  # upload/download round trip is exact
+    lib = orc.lib
+    for gamma in (False, True):
+        got = device.film_rgb8(1.0 / spp, gamma=gamma)
+        want = np.empty_like(got)
+        c3, o3 = (C.c_double * 3)(), (C.c_uint8 * 3)()
+        scaled = sums.astype(np.float64) * (1.0 / spp)
+        for idx in np.ndindex(h, w):
+            c3[:] = scaled[idx]
+            lib.orc_color_quantize(c3, int(gamma), o3)
+            want[idx] = o3[:]
+        assert np.array_equal(got, want), (gamma, np.argwhere(got != want)[:5])
+
+
+def test_progressive_render_resumes_from_a_checkpoint(device, tmp_path):
+    host, osb, cam, mode, _ = scene("c3", device)
+    device.film_resize(cam.image_width, cam.image_height)
+    device.render(cam.build(), mode=mode, seed=9)
+    whole = device.film(1.0).astype(np.float64)
+    ck_path = tmp_path / "render.npz"
+    calls = []
+
+    class Stop(Exception):
+        pass
+
+    def interrupt(done, total):
+        calls.append(done)
+        if done >= 8:
+            raise Stop
+
+    with pytest.raises(Stop):  # killed after two batches of four strata
+        ra.progressive.render_progressive(device, cam, mode, seed=9, batch_strata=4, checkpoint_path=ck_path, on_batch=interrupt)
+    assert ra.progressive.Checkpoint.load(ck_path).next_stratum == 8
+    device.film_clear()  # nothing of the first run survives on the device
+    final = ra.progressive.render_progressive(device, cam, mode, seed=9, batch_strata=4, checkpoint_path=ck_path,
+                                              preview_path=tmp_path / "preview.png", on_batch=lambda d, t: calls.append(d))
+    assert calls == [4, 8, 12, 16] and final.next_stratum == cam.effective_spp
+    assert np.allclose(final.sums, whole, rtol=2e-5, atol=1e-5)
+    png = ra.imageio.read_png(tmp_path / "preview.png")
+    assert np.array_equal(png, device.film_rgb8(1.0 / cam.effective_spp))
+    with pytest.raises(ValueError):
+        ra.progressive.render_progressive(device, cam, mode, seed=10, checkpoint_path=ck_path)

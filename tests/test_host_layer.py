@@ -463,6 +463,31 @@ def test_png_ppm_writers_and_reader(tmp_path):
         sb._call("tex_image_png", C.c_char_p(b"/nonexistent.png"))
 
 
+def test_byte_image_files_round_trip(tmp_path):
+    """Files written from already-quantised bytes (the device output stage) read back equal."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    px = (rng.random((9, 13, 3)) * 256).astype(np.uint8)
+    ra.imageio.write_png(tmp_path / "q.png", px)
+    assert np.array_equal(ra.imageio.read_png(tmp_path / "q.png"), px)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "q.png")), px)
+    ra.imageio.write_ppm(tmp_path / "q.ppm", px)
+    toks = (tmp_path / "q.ppm").read_text().split()
+    assert toks[:4] == ["P3", "13", "9", "255"] and np.array_equal(np.array(toks[4:], dtype=np.uint8).reshape(px.shape), px)
+    with pytest.raises(OSError):
+        ra.imageio.read_png(tmp_path / "missing.png")
+    with pytest.raises(OSError):
+        ra.imageio.write_png(tmp_path / "no_such_dir" / "x.png", px)
+
+
+def test_checkpoint_file_round_trip(tmp_path):
+    from raytracing_amd.progressive import Checkpoint
+    ck = Checkpoint(np.arange(24, dtype=np.float32).reshape(2, 4, 3), 5, 16, 1234567890123, 1)
+    ck.save(tmp_path / "c.npz")
+    back = Checkpoint.load(tmp_path / "c.npz")
+    assert np.array_equal(back.sums, ck.sums) and (back.next_stratum, back.n_strata, back.seed, back.mode) == (5, 16, 1234567890123, 1)
+
+
 def test_partition_strata():
     from raytracing_amd.distributed import partition_strata
     for n, w in ((961, 8), (16, 2), (16, 3), (5, 8), (4096, 8)):
