@@ -17,7 +17,7 @@ DEV_OBJ = raytracing_amd/csrc/rt_device.o
 
 all: $(LIB) oracle
 
-$(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_math.h include/rt_amd.h
+$(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 raytracing_amd/host/%.o: raytracing_amd/host/%.cpp raytracing_amd/host/raytracing.hpp include/rt_amd.h

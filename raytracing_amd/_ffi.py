@@ -81,6 +81,13 @@ class CameraBuilderStruct(C.Structure):
 
 
 RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
+
+
+class RtAccelInfo(C.Structure):
+    _fields_ = [("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32)]
+
+
+RT_BUILD_REFERENCE, RT_BUILD_SAH = 0, 1
 RT_FLAG_TIME_KERNELS = 1
 RT_FLAG_WAVEFRONT = 2
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
@@ -102,6 +109,8 @@ SIGNATURES = {
     "rt_film_resize": (C.c_int, [_vp, u32, u32]),
     "rt_film_bind": (C.c_int, [_vp, _vp, u32, u32]),
     "rt_film_device_ptr": (C.c_int, [_vp, P(_vp), P(u64)]),
+    "rt_set_accel": (C.c_int, [_vp, u32, u32]),
+    "rt_get_accel_info": (C.c_int, [_vp, P(RtAccelInfo)]),
     "rt_film_download": (C.c_int, [_vp, P(f32), f32]),
     "rt_film_upload": (C.c_int, [_vp, P(f32), u32, u32]),
     "rt_film_quantize": (C.c_int, [_vp, P(C.c_uint8), f64, u32]),

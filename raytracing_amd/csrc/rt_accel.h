@@ -1,0 +1,365 @@
+// rt_accel.h -- host side of the 4-wide BVH the device traverses (built at scene upload).
+//
+// The scene descriptor carries the reference's structure: binary BVHNode nodes in the topology
+// BVHNode::new built (boundingbox.rs:179-206) and HittableVec lists (hittable.rs:252-264).
+// The closest hit does not depend on how the primitives are grouped, so the upload derives a
+// structure that suits the hardware better and leaves the descriptor as it is:
+//   * every box is recomputed from the fp32 primitive records the kernels test, rounded outward;
+//   * a list becomes a small tree over its entries (median splits), so lists are culled by boxes
+//     like everything else and the device has one node type;
+//   * binary nodes are collapsed into 4-wide nodes: the child with the largest box is replaced by
+//     its own children until four slots are used -- half the dependent node fetches per ray;
+//   * optionally (RT_BUILD_SAH) the binary tree is rebuilt over all primitives with a binned
+//     surface-area heuristic before the collapse.
+// Nodes are numbered breadth first.
+#pragma once
+#include "../../include/rt_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <queue>
+#include <string>
+#include <vector>
+
+namespace rt {
+
+// 128 bytes: child boxes as structure of arrays, then the child references.  An unused slot has
+// ref RT_REF_NONE and an inverted box (+inf .. -inf) that no ray enters.
+struct Node4 {
+    float lo[3][4];
+    float hi[3][4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "wide node is one 128-byte line");
+
+namespace accel {
+
+struct Box {
+    float lo[3], hi[3];
+    Box() {
+        for (int i = 0; i < 3; ++i) lo[i] = std::numeric_limits<float>::infinity(), hi[i] = -lo[i];
+    }
+    void add(const Box &b) {
+        for (int i = 0; i < 3; ++i) lo[i] = std::min(lo[i], b.lo[i]), hi[i] = std::max(hi[i], b.hi[i]);
+    }
+    void add(const double p[3]) {
+        for (int i = 0; i < 3; ++i) {
+            // outward to fp32, plus one ulp: the device evaluates hit points in fp32
+            float d = std::nextafter(float(p[i]), -std::numeric_limits<float>::infinity());
+            float u = std::nextafter(float(p[i]), std::numeric_limits<float>::infinity());
+            lo[i] = std::min(lo[i], d), hi[i] = std::max(hi[i], u);
+        }
+    }
+    bool valid() const { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+    double area() const {
+        if (!valid()) return 0.0;
+        double x = double(hi[0]) - lo[0], y = double(hi[1]) - lo[1], z = double(hi[2]) - lo[2];
+        return 2.0 * (x * y + y * z + z * x);
+    }
+    double centre(int a) const { return 0.5 * (double(lo[a]) + double(hi[a])); }
+    // BoundingBox3::new pads thin axes to 1e-4 (boundingbox.rs:14-30)
+    void pad() {
+        for (int i = 0; i < 3; ++i)
+            if (double(hi[i]) - double(lo[i]) < 1e-4) {
+                double c = centre(i);
+                lo[i] = std::nextafter(float(c - 5e-5), -std::numeric_limits<float>::infinity());
+                hi[i] = std::nextafter(float(c + 5e-5), std::numeric_limits<float>::infinity());
+            }
+    }
+};
+
+// A child slot of the intermediate tree: a primitive/medium ref, or an inner node (index into `inner`).
+struct Slot {
+    uint32_t ref;   // primitive ref, or RT_REF_NONE when `node` is used
+    int32_t node;   // index into Builder::inner, -1 for a primitive
+    Box box;
+};
+struct Inner {
+    int32_t a, b; // indices into Builder::slots
+};
+
+struct Stats {
+    uint32_t nodes = 0, depth = 0, stack_need = 0, leaves = 0;
+};
+
+struct Builder {
+    const rt_scene_desc *s;
+    std::vector<Slot> slots;
+    std::vector<Inner> inner;
+    std::vector<int32_t> node_slot; // descriptor node index -> slot (memo: nodes may be shared)
+    std::string error;
+
+    explicit Builder(const rt_scene_desc *scene) : s(scene), node_slot(scene->n_nodes, -1) {}
+
+    Box prim_box(uint32_t ref) const {
+        const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+        Box b;
+        if (kind == RT_KIND_QUAD) { // the parallelogram Q, Q+u, Q+v, Q+u+v bounds triangle and disc too
+            const rt_quad &q = s->quads[idx];
+            for (int k = 0; k < 4; ++k) {
+                double p[3];
+                for (int i = 0; i < 3; ++i) p[i] = double(q.q[i]) + ((k & 1) ? double(q.u[i]) : 0.0) + ((k & 2) ? double(q.v[i]) : 0.0);
+                b.add(p);
+            }
+            b.pad();
+        } else if (kind == RT_KIND_SPHERE) { // both ends of the motion (hittable.rs:136-147)
+            const rt_sphere &sp = s->spheres[idx];
+            const double r = double(sp.radius) * (1.0 + 1e-6);
+            for (int e = 0; e < 2; ++e)
+                for (int sgn = -1; sgn <= 1; sgn += 2) {
+                    double p[3];
+                    for (int i = 0; i < 3; ++i) p[i] = double(sp.c0[i]) + e * double(sp.cv[i]) + sgn * r;
+                    b.add(p);
+                }
+        } else if (kind == RT_KIND_MEDIUM) {
+            const rt_medium &m = s->media[idx];
+            for (uint32_t k = 0; k < m.count; ++k) b.add(prim_box(s->refs[m.first + k]));
+        }
+        return b;
+    }
+
+    int32_t new_slot(uint32_t ref, int32_t node, const Box &box) {
+        slots.push_back(Slot{ref, node, box});
+        return int32_t(slots.size() - 1);
+    }
+    int32_t join(int32_t a, int32_t b) {
+        Box box = slots[a].box;
+        box.add(slots[b].box);
+        inner.push_back(Inner{a, b});
+        return new_slot(RT_REF_NONE, int32_t(inner.size() - 1), box);
+    }
+
+    // a binary tree over `items` (slot indices): median split of the centres on the longest axis
+    int32_t median_tree(std::vector<int32_t> &items, size_t lo, size_t hi) {
+        if (hi - lo == 1) return items[lo];
+        Box cb;
+        for (size_t i = lo; i < hi; ++i) {
+            double c[3] = {slots[items[i]].box.centre(0), slots[items[i]].box.centre(1), slots[items[i]].box.centre(2)};
+            cb.add(c);
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (double(cb.hi[a]) - cb.lo[a] > double(cb.hi[axis]) - cb.lo[axis]) axis = a;
+        size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                         [&](int32_t x, int32_t y) { return slots[x].box.centre(axis) < slots[y].box.centre(axis); });
+        int32_t l = median_tree(items, lo, mid), r = median_tree(items, mid, hi);
+        return join(l, r);
+    }
+
+    // binned surface-area heuristic, 16 bins, leaves of one primitive (the device has no leaf lists)
+    int32_t sah_tree(std::vector<int32_t> &items, size_t lo, size_t hi) {
+        const size_t n = hi - lo;
+        if (n == 1) return items[lo];
+        if (n <= 4) return median_tree(items, lo, hi);
+        Box cb;
+        for (size_t i = lo; i < hi; ++i) {
+            double c[3] = {slots[items[i]].box.centre(0), slots[items[i]].box.centre(1), slots[items[i]].box.centre(2)};
+            cb.add(c);
+        }
+        constexpr int BINS = 16;
+        double best = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = 0;
+        for (int axis = 0; axis < 3; ++axis) {
+            const double c0 = cb.lo[axis], ext = double(cb.hi[axis]) - c0;
+            if (!(ext > 0.0)) continue;
+            Box bb[BINS];
+            size_t cnt[BINS] = {};
+            for (size_t i = lo; i < hi; ++i) {
+                int k = std::min(BINS - 1, int((slots[items[i]].box.centre(axis) - c0) / ext * BINS));
+                k = std::max(k, 0);
+                bb[k].add(slots[items[i]].box);
+                ++cnt[k];
+            }
+            double right_area[BINS];
+            size_t right_cnt[BINS];
+            Box acc;
+            size_t c = 0;
+            for (int k = BINS - 1; k > 0; --k) {
+                acc.add(bb[k]);
+                c += cnt[k];
+                right_area[k] = acc.area(), right_cnt[k] = c;
+            }
+            acc = Box();
+            c = 0;
+            for (int k = 0; k < BINS - 1; ++k) {
+                acc.add(bb[k]);
+                c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                double cost = acc.area() * double(c) + right_area[k + 1] * double(right_cnt[k + 1]);
+                if (cost < best) best = cost, best_axis = axis, best_bin = k;
+            }
+        }
+        if (best_axis < 0) return median_tree(items, lo, hi); // all centres coincide
+        const double c0 = cb.lo[best_axis], ext = double(cb.hi[best_axis]) - c0;
+        auto mid_it = std::partition(items.begin() + lo, items.begin() + hi, [&](int32_t x) {
+            int k = std::min(BINS - 1, int((slots[x].box.centre(best_axis) - c0) / ext * BINS));
+            return std::max(k, 0) <= best_bin;
+        });
+        size_t mid = size_t(mid_it - items.begin());
+        if (mid == lo || mid == hi) return median_tree(items, lo, hi);
+        int32_t l = sah_tree(items, lo, mid), r = sah_tree(items, mid, hi);
+        return join(l, r);
+    }
+
+    // descriptor reference -> slot of the intermediate binary tree (reference topology)
+    int32_t from_ref(uint32_t ref, uint32_t depth) {
+        if ((ref >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) return new_slot(ref, -1, prim_box(ref));
+        const uint32_t idx = ref & RT_REF_INDEX_MASK;
+        if (node_slot[idx] >= 0) return node_slot[idx];
+        if (depth > 4096) {
+            error = "scene graph deeper than 4096 levels";
+            return -1;
+        }
+        const rt_node &n = s->nodes[idx];
+        int32_t out;
+        if (n.right == RT_NODE_LEAF) {
+            if (n.count == 0) {
+                error = "empty list in the world";
+                return -1;
+            }
+            std::vector<int32_t> items;
+            for (uint32_t k = 0; k < n.count; ++k) {
+                int32_t c = from_ref(s->refs[n.left + k], depth + 1);
+                if (c < 0) return -1;
+                items.push_back(c);
+            }
+            out = median_tree(items, 0, items.size());
+        } else {
+            int32_t l = from_ref(n.left, depth + 1);
+            if (l < 0) return -1;
+            int32_t r = from_ref(n.right, depth + 1);
+            if (r < 0) return -1;
+            out = join(l, r);
+        }
+        node_slot[idx] = out;
+        return out;
+    }
+
+    void collect_prims(int32_t slot, std::vector<int32_t> &out) const {
+        std::vector<int32_t> todo{slot};
+        while (!todo.empty()) {
+            int32_t x = todo.back();
+            todo.pop_back();
+            if (slots[x].node < 0) {
+                out.push_back(x);
+            } else {
+                todo.push_back(inner[slots[x].node].a);
+                todo.push_back(inner[slots[x].node].b);
+            }
+        }
+    }
+
+    // Collapse to 4-wide nodes, numbered breadth first.  Returns the root ref.
+    uint32_t collapse(int32_t root, std::vector<Node4> &nodes, Stats &st) {
+        nodes.clear();
+        struct Pending {
+            int32_t slot;
+            uint32_t depth;
+        };
+        std::queue<Pending> qu;
+        if (slots[root].node < 0) {
+            // a world of one primitive: one node holding it
+            Node4 n;
+            fill_empty(n);
+            set_child(n, 0, slots[root].ref, slots[root].box);
+            nodes.push_back(n);
+            st.nodes = 1, st.depth = 1, st.stack_need = 1, st.leaves = 1;
+            return (RT_KIND_NODE << RT_REF_KIND_SHIFT) | 0u;
+        }
+        qu.push({root, 1});
+        uint32_t next_index = 1; // index the next queued node will get
+        std::vector<uint32_t> depth_of;
+        while (!qu.empty()) {
+            Pending p = qu.front();
+            qu.pop();
+            int32_t ch[4];
+            int n = 0;
+            ch[n++] = inner[slots[p.slot].node].a;
+            ch[n++] = inner[slots[p.slot].node].b;
+            while (n < 4) { // open the inner child with the largest box
+                int pick = -1;
+                double area = -1.0;
+                for (int i = 0; i < n; ++i)
+                    if (slots[ch[i]].node >= 0 && slots[ch[i]].box.area() > area) area = slots[ch[i]].box.area(), pick = i;
+                if (pick < 0) break;
+                const Inner in = inner[slots[ch[pick]].node];
+                ch[pick] = in.a;
+                ch[n++] = in.b;
+            }
+            Node4 nd;
+            fill_empty(nd);
+            for (int i = 0; i < n; ++i) {
+                const Slot &c = slots[ch[i]];
+                if (c.node < 0) {
+                    set_child(nd, i, c.ref, c.box);
+                    ++st.leaves;
+                } else {
+                    set_child(nd, i, (RT_KIND_NODE << RT_REF_KIND_SHIFT) | next_index, c.box);
+                    ++next_index;
+                    qu.push({ch[i], p.depth + 1});
+                }
+            }
+            nodes.push_back(nd);
+            st.depth = std::max(st.depth, p.depth);
+        }
+        st.nodes = uint32_t(nodes.size());
+        // a visit pushes at most three siblings and goes one level down
+        st.stack_need = 3 * st.depth + 1;
+        return (RT_KIND_NODE << RT_REF_KIND_SHIFT) | 0u;
+    }
+
+    static void fill_empty(Node4 &n) {
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; ++a)
+            for (int i = 0; i < 4; ++i) n.lo[a][i] = inf, n.hi[a][i] = -inf;
+        for (int i = 0; i < 4; ++i) n.child[i] = RT_REF_NONE, n.pad[i] = 0;
+    }
+    static void set_child(Node4 &n, int i, uint32_t ref, const Box &b) {
+        for (int a = 0; a < 3; ++a) n.lo[a][i] = b.lo[a], n.hi[a][i] = b.hi[a];
+        n.child[i] = ref;
+    }
+};
+
+// Exact stack need of near-first traversal: the most entries that can be on the stack at once is
+// the maximum over root-to-leaf paths of the sum of (children - 1) along the path.
+inline uint32_t stack_need(const std::vector<Node4> &nodes) {
+    std::vector<uint32_t> need(nodes.size(), 0);
+    for (size_t i = nodes.size(); i-- > 0;) { // children have larger indices (breadth-first numbering)
+        uint32_t kids = 0, deepest = 0;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t c = nodes[i].child[k];
+            if (c == RT_REF_NONE) continue;
+            ++kids;
+            if ((c >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) deepest = std::max(deepest, need[c & RT_REF_INDEX_MASK]);
+        }
+        need[i] = (kids ? kids - 1 : 0) + deepest;
+    }
+    return nodes.empty() ? 0 : need[0] + 1;
+}
+
+// Builds the wide BVH of the (validated) scene.  builder: RT_BUILD_REFERENCE keeps the grouping
+// of the descriptor's binary nodes, RT_BUILD_SAH regroups all primitives.  Returns "" or an error.
+inline std::string build_wide_bvh(const rt_scene_desc *s, uint32_t builder, std::vector<Node4> &nodes, uint32_t &root,
+                                  Stats &st) {
+    Builder b(s);
+    b.slots.reserve(size_t(s->n_quads + s->n_spheres + s->n_media) * 2 + 16);
+    int32_t top = b.from_ref(s->root, 0);
+    if (top < 0) return b.error;
+    if (builder == RT_BUILD_SAH && b.slots[top].node >= 0) {
+        std::vector<int32_t> prims;
+        b.collect_prims(top, prims);
+        top = b.sah_tree(prims, 0, prims.size());
+    }
+    st = Stats();
+    root = b.collapse(top, nodes, st);
+    st.stack_need = stack_need(nodes);
+    return "";
+}
+
+} // namespace accel
+} // namespace rt

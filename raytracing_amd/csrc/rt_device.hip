@@ -1,6 +1,7 @@
 // rt_device.hip -- device half of the C ABI (rt_* in include/rt_amd.h): scene upload,
 // the wavefront render loop, film handling and the parity hooks.
 #include "rt_kernels.h"
+#include "rt_accel.h"
 
 #include <cmath>
 #include <cstdio>
@@ -34,6 +35,10 @@ struct rt_handle {
     DCamera *d_cam = nullptr;
     bool have_scene = false;
     bool flat = false;
+    int accel = ACCEL_BVH2;                 // structure the kernels search for this scene
+    uint32_t build = RT_BUILD_REFERENCE, width = 4; // rt_set_accel: applies to the next upload
+    uint32_t stack4 = 0;                    // LDS stack entries per lane of the wide traversal
+    accel::Stats accel_stats{};
     uint32_t has_media = 0, n_prims = 0;
     bool has_specular = false;
     uint32_t n_textures = 0;
@@ -119,9 +124,6 @@ int validate_scene(rt_handle *h, const rt_scene_desc *s) {
         return fail(h, "rt_upload_scene: null array with non-zero count");
     if (s->n_materials == 0) return fail(h, "rt_upload_scene: scene has no materials");
     if (!ref_ok(s, s->root, true, true)) return fail(h, "rt_upload_scene: root reference out of range");
-    if (s->max_stack > uint32_t(STACK_DEPTH))
-        return fail(h, "rt_upload_scene: scene needs a deeper traversal stack than the kernels provide (" +
-                           std::to_string(s->max_stack) + " > " + std::to_string(STACK_DEPTH) + ")");
     for (uint32_t i = 0; i < s->n_nodes; ++i) {
         const rt_node &n = s->nodes[i];
         if (n.right == RT_NODE_LEAF) {
@@ -303,12 +305,13 @@ void drain_timers(rt_handle *h) {
 }
 
 // One launch of the persistent path kernel: as many blocks as the device keeps resident.
-template <int MODE, bool FLAT>
+template <int MODE, int ACCEL>
 int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
                  unsigned long long total) {
-    auto kernel = k_paths<MODE, FLAT>;
+    auto kernel = k_paths<MODE, ACCEL>;
     int per_cu = 0, n_cu = 0;
-    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
+    const size_t dyn_lds = ACCEL == ACCEL_BVH4 ? size_t(h->stack4) * BLOCK * sizeof(uint32_t) : 0;
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
     if (p->waves_per_simd && int(p->waves_per_simd) < per_cu) per_cu = int(p->waves_per_simd); // a block is one wave per SIMD
@@ -322,7 +325,7 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
     if (refill_min > uint32_t(WAVE)) refill_min = WAVE;
     Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
     int e = tm.begin(4);
-    kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), 0, h->stream>>>(h->d_sc, h->d_cam, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
+    kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), dyn_lds, h->stream>>>(h->d_sc, h->d_cam, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
                                                                 h->d_ctrl, h->has_media,
                                                                 uint32_t(grab), refill_min);
     tm.end(e);
@@ -335,12 +338,12 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
                       unsigned long long total) {
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
     int rc;
-    if (p->mode == RT_MODE_REF_EXACT)
-        rc = h->flat ? launch_paths<RT_MODE_REF_EXACT, true>(h, dc, p, film, total)
-                     : launch_paths<RT_MODE_REF_EXACT, false>(h, dc, p, film, total);
-    else
-        rc = h->flat ? launch_paths<RT_MODE_BOOK3, true>(h, dc, p, film, total)
-                     : launch_paths<RT_MODE_BOOK3, false>(h, dc, p, film, total);
+#define RT_PATHS(MODE)                                                                                    \
+    (h->accel == ACCEL_FLAT   ? launch_paths<MODE, ACCEL_FLAT>(h, dc, p, film, total)                        \
+     : h->accel == ACCEL_BVH4 ? launch_paths<MODE, ACCEL_BVH4>(h, dc, p, film, total)                        \
+                              : launch_paths<MODE, ACCEL_BVH2>(h, dc, p, film, total))
+    rc = p->mode == RT_MODE_REF_EXACT ? RT_PATHS(RT_MODE_REF_EXACT) : RT_PATHS(RT_MODE_BOOK3);
+#undef RT_PATHS
     if (rc) return rc;
     RT_HIP(hipEventRecord(h->ev_end, h->stream));
     RT_HIP(hipMemcpyAsync(&h->h_ctrl[0], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
@@ -459,6 +462,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     const rt_quad *dq;
     const rt_sphere *ds;
     const float *dnv;
+    const Node4 *dn4;
     // device copy of the materials: a SolidColor texture is folded into the material record
     // (albedo + pad = 1) so that shading such a surface does not chase the texture record
     std::vector<rt_material> mats(s->materials, s->materials + s->n_materials);
@@ -500,13 +504,38 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
             }
         }
     }
+    // structure the kernels will search
+    std::vector<Node4> nodes4;
+    h->stack4 = 0;
+    h->accel_stats = accel::Stats();
+    if (h->flat) {
+        h->accel = ACCEL_FLAT;
+    } else if (h->width == 4) {
+        uint32_t root4 = 0;
+        std::string err = accel::build_wide_bvh(s, h->build, nodes4, root4, h->accel_stats);
+        if (!err.empty()) return fail(h, "rt_upload_scene: " + err);
+        // one LDS column per lane: 160 KB per CU / 1024 lanes at 4 waves per SIMD = 40 entries
+        if (h->accel_stats.stack_need <= 40) {
+            h->accel = ACCEL_BVH4;
+            h->stack4 = std::max(8u, (h->accel_stats.stack_need + 3u) & ~3u);
+        } else {
+            nodes4.clear(); // too deep for the LDS stack of the wide traversal: binary nodes as given
+            h->accel = ACCEL_BVH2;
+        }
+    } else {
+        h->accel = ACCEL_BVH2;
+    }
+    if (h->accel == ACCEL_BVH2 && s->max_stack > uint32_t(STACK_DEPTH))
+        return fail(h, "rt_upload_scene: scene needs a deeper traversal stack than the kernels provide (" +
+                           std::to_string(s->max_stack) + " > " + std::to_string(STACK_DEPTH) + ")");
+    d.n_nodes4 = uint32_t(nodes4.size());
     d.n_flat_quads = uint32_t(flat_quads.size() / 16);
     // the scan requests records in pairs, one pair ahead: pad with records that cannot hit
     flat_quads.resize((size_t(d.n_flat_quads) + 3) / 2 * 2 * 16, 0.0f);
     d.n_flat_other = uint32_t(flat_other.size());
     if (upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, s->spheres, s->n_spheres, &ds) ||
-        upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) ||
+        upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, nodes4.data(), nodes4.size(), &dn4) ||
         upload(h, flat_other.data(), flat_other.size(), &d.flat_other) ||
         upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
         upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) ||
@@ -518,6 +547,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.quads = reinterpret_cast<const float4 *>(dq);
     d.spheres = reinterpret_cast<const float4 *>(ds);
     d.noise_vec = reinterpret_cast<const float4 *>(dnv);
+    d.nodes4 = reinterpret_cast<const float4 *>(dn4);
     d.root = s->root;
     d.n_lights = s->n_lights;
     d.lights_kind = s->lights_kind;
@@ -539,6 +569,27 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     for (uint32_t i = 0; i < s->n_quads; ++i) note(s->quads[i].prim_id, (RT_KIND_QUAD << RT_REF_KIND_SHIFT) | i);
     for (uint32_t i = 0; i < s->n_spheres; ++i) note(s->spheres[i].prim_id, (RT_KIND_SPHERE << RT_REF_KIND_SHIFT) | i);
     for (uint32_t i = 0; i < s->n_media; ++i) note(s->media[i].prim_id, (RT_KIND_MEDIUM << RT_REF_KIND_SHIFT) | i);
+    return 0;
+}
+
+int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width) {
+    if (!h) return -1;
+    if (builder > RT_BUILD_SAH) return fail(h, "rt_set_accel: unknown builder");
+    if (width != 2 && width != 4) return fail(h, "rt_set_accel: width must be 2 or 4");
+    if (width == 2 && builder != RT_BUILD_REFERENCE)
+        return fail(h, "rt_set_accel: the binary traversal walks the descriptor's own nodes; regrouping needs width 4");
+    h->build = builder;
+    h->width = width;
+    return 0;
+}
+
+int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
+    if (!h || !out) return -1;
+    if (!h->have_scene) return fail(h, "rt_get_accel_info: no scene uploaded");
+    out->kind = uint32_t(h->accel);
+    out->nodes = h->accel == ACCEL_BVH4 ? h->accel_stats.nodes : (h->accel == ACCEL_BVH2 ? h->sc.n_nodes : 0u);
+    out->depth = h->accel == ACCEL_BVH4 ? h->accel_stats.depth : 0u;
+    out->stack_entries = h->accel == ACCEL_BVH4 ? h->stack4 : (h->accel == ACCEL_BVH2 ? uint32_t(STACK_DEPTH) : 0u);
     return 0;
 }
 
@@ -695,6 +746,7 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     const bool timing = (p->flags & RT_FLAG_TIME_KERNELS) != 0;
     const uint32_t time_every = p->time_every ? p->time_every : 1u;
     Timer tm{h, false};
+    const size_t dyn_lds = size_t(h->stack4) * BLOCK * sizeof(uint32_t); // wide traversal stack
     uint64_t iter_no = p->seed; // rotate which iterations are timed from render to render
 
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
@@ -714,10 +766,12 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
             k_generate<<<grid, block, 0, h->stream>>>(h->q, h->d_cam, k0, k1);
             tm.end(e);
             e = tm.begin(1);
-            if (h->flat)
-                k_extend<true><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
+            if (h->accel == ACCEL_FLAT)
+                k_extend<ACCEL_FLAT><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
+            else if (h->accel == ACCEL_BVH4)
+                k_extend<ACCEL_BVH4><<<grid, block, dyn_lds, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
             else
-                k_extend<false><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
+                k_extend<ACCEL_BVH2><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
             tm.end(e);
             e = tm.begin(2);
             if (p->mode == RT_MODE_REF_EXACT)
@@ -793,11 +847,16 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (e == hipSuccess && time) e = hipMemcpyAsync(d_time, time, size_t(n) * sizeof(float), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
-        if (h->flat)
-            k_intersect_batch<true><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+        const size_t dyn_lds = size_t(h->stack4) * BLOCK * sizeof(uint32_t);
+        if (h->accel == ACCEL_FLAT)
+            k_intersect_batch<ACCEL_FLAT><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
+                                                                         d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+        else if (h->accel == ACCEL_BVH4)
+            k_intersect_batch<ACCEL_BVH4><<<grid, block, dyn_lds, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax,
+                                                                               d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         else
-            k_intersect_batch<false><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
-                                                                    d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+            k_intersect_batch<ACCEL_BVH2><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
+                                                                         d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hit, d_i, size_t(n) * sizeof(int), hipMemcpyDeviceToHost, h->stream);

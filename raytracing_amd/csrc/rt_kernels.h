@@ -49,8 +49,13 @@ struct DScene {
     // (q.xyz ref | n.xyz mat | avec.xyz shape | bvec.xyz -), and the refs of everything else
     const float *flat_quads;
     const uint32_t *flat_other;
-    uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_other;
+    // 4-wide BVH derived at upload (rt_accel.h): 8 float4 per node, root = node 0
+    const float4 *nodes4;
+    uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_other, n_nodes4;
 };
+
+// which structure a kernel instance searches
+enum : int { ACCEL_FLAT = 0, ACCEL_BVH2 = 1, ACCEL_BVH4 = 2 };
 
 struct DCamera {
     V3 p00_rel, du, dv, center, disk_u, disk_v, bg;
@@ -295,8 +300,12 @@ __device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, f
     }
 }
 
-// BoundingBox3::hit (boundingbox.rs:96-113) with a cached reciprocal direction; the box is
-// entered only if the overlap has positive size (touching rejects, as in the reference).
+// BoundingBox3::hit (boundingbox.rs:96-113) with a cached reciprocal direction.  The reference
+// rejects an overlap of size 0 in f64; in fp32 the two ends of a crossing of a thin box (a quad's
+// box is 1e-4 thick) can round to the same t, or cross by a few ulp when they come from
+// different axes, so here the overlap may be empty by up to BOX_SLACK relative.  Entering a box
+// needlessly costs time only: hits come from the primitive tests.
+constexpr float BOX_SLACK = 1e-6f;
 __device__ __forceinline__ bool hit_box(const float *mn, const float *mx, V3 o, V3 inv, float tlo, float thi,
                                         float &tnear) {
     float x0 = (mn[0] - o.x) * inv.x, x1 = (mx[0] - o.x) * inv.x;
@@ -305,7 +314,7 @@ __device__ __forceinline__ bool hit_box(const float *mn, const float *mx, V3 o, 
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tlo));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), thi));
     tnear = tn;
-    return tn < tf;
+    return tn <= fmaf(fabsf(tf), BOX_SLACK, tf);
 }
 
 // Closest hit of the world.  `stack` is this lane's column of an LDS array [STACK_DEPTH][BLOCK];
@@ -365,6 +374,74 @@ __device__ __forceinline__ void traverse(SceneRef sc, V3 o, V3 d, float time, fl
         cur = stack[(--sp) * BLOCK];
     }
 }
+
+// Closest hit through the 4-wide BVH.  `stack` is this lane's column of an LDS array
+// [depth][BLOCK] whose depth the host sized to the scene's exact need (rt_accel.h).
+// Two nested loops: the inner one walks interior nodes only, the primitive test runs once all
+// lanes of the wave have left it, so a wave does not execute node code and primitive code for
+// one lane each per iteration.  Children are visited nearest first; the others go on the stack
+// farthest first.  Visiting order cannot change the closest hit.
+__device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
+                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *stack, Best &best) {
+    best.t = thi;
+    best.ref = best.mat = RT_REF_NONE;
+    best.u = best.v = 0.f;
+    const V3 inv = {rcp(d.x), rcp(d.y), rcp(d.z)};
+    const float4 *nodes = sc.nodes4;
+    uint32_t sp = 0;
+    uint32_t cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
+    for (;;) {
+        while ((cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) {
+            const float4 *n = nodes + 8 * size_t(cur & RT_REF_INDEX_MASK);
+            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cf = n[6];
+            const float lo_x[4] = {lx.x, lx.y, lx.z, lx.w}, lo_y[4] = {ly.x, ly.y, ly.z, ly.w}, lo_z[4] = {lz.x, lz.y, lz.z, lz.w};
+            const float hi_x[4] = {hx.x, hx.y, hx.z, hx.w}, hi_y[4] = {hy.x, hy.y, hy.z, hy.w}, hi_z[4] = {hz.x, hz.y, hz.z, hz.w};
+            uint32_t ref[4] = {fbits(cf.x), fbits(cf.y), fbits(cf.z), fbits(cf.w)};
+            uint32_t key[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { // BoundingBox3::hit (boundingbox.rs:96-113), see hit_box
+                const float x0 = (lo_x[i] - o.x) * inv.x, x1 = (hi_x[i] - o.x) * inv.x;
+                const float y0 = (lo_y[i] - o.y) * inv.y, y1 = (hi_y[i] - o.y) * inv.y;
+                const float z0 = (lo_z[i] - o.z) * inv.z, z1 = (hi_z[i] - o.z) * inv.z;
+                const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tlo));
+                const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
+                const bool hit = (tn <= fmaf(fabsf(tf), BOX_SLACK, tf)) & (ref[i] != RT_REF_NONE);
+                key[i] = hit ? fbits(tn) : 0xFFFFFFFFu; // tn >= tlo > 0: float order = unsigned order
+            }
+            // sort the four (key, ref) pairs ascending: 5 compare-exchanges
+#define RT_CSWAP(a, b)                                                                       \
+    {                                                                                        \
+        const bool sw = key[b] < key[a];                                                     \
+        const uint32_t ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                 \
+        const uint32_t ra_ = sw ? ref[b] : ref[a], rb_ = sw ? ref[a] : ref[b];               \
+        key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                                \
+    }
+            RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+            if (key[3] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[3];
+            if (key[2] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[2];
+            if (key[1] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[1];
+            if (key[0] != 0xFFFFFFFFu) {
+                cur = ref[0];
+            } else if (sp) {
+                cur = stack[(--sp) * BLOCK];
+            } else {
+                cur = RT_REF_NONE;
+            }
+        }
+        if (cur == RT_REF_NONE) break;
+        test_prim(sc, cur, o, d, time, tlo, origin_ref, rc, best);
+        if (sp == 0) break;
+        cur = stack[(--sp) * BLOCK];
+    }
+}
+
+// One entry for the three structures.  s_stack / s_nodes: static LDS of the binary traversal;
+// s_dyn: dynamic LDS of the wide traversal.
+template <int ACCEL, bool USE_LDS_NODES>
+__device__ __forceinline__ void closest_hit(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi, uint32_t origin_ref,
+                                            const RayCtx &rc, uint32_t *s_stack, const rt_node *s_nodes, uint32_t *s_dyn,
+                                            Best &best);
 
 // Flat world (a HittableVec of primitives, e.g. main.rs:30-69): every lane walks the same list,
 // so each primitive is one scalar record applied to 64 rays.  The quad test is written without
@@ -434,6 +511,24 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
     const RT_CONST_AS uint32_t *other = as_uniform(sc.flat_other);
     for (uint32_t k = 0; k < sc.n_flat_other; ++k) test_prim<true>(sc, other[k], o, d, time, tlo, origin_ref, rc, best);
 }
+
+template <int ACCEL, bool USE_LDS_NODES>
+__device__ __forceinline__ void closest_hit(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi, uint32_t origin_ref,
+                                            const RayCtx &rc, uint32_t *s_stack, const rt_node *s_nodes, uint32_t *s_dyn,
+                                            Best &best) {
+    if (ACCEL == ACCEL_FLAT)
+        scan_flat(sc, o, d, time, tlo, thi, origin_ref, rc, best);
+    else if (ACCEL == ACCEL_BVH2)
+        traverse<USE_LDS_NODES>(sc, o, d, time, tlo, thi, origin_ref, rc, s_stack + threadIdx.x, s_nodes, best);
+    else
+        traverse4(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn + threadIdx.x, best);
+}
+
+// LDS the three structures need, declared once per kernel
+#define RT_ACCEL_LDS(ACCEL)                                                                  \
+    __shared__ uint32_t s_stack[(ACCEL) == ACCEL_BVH2 ? STACK_DEPTH * BLOCK : 1];            \
+    __shared__ rt_node s_nodes[(ACCEL) == ACCEL_BVH2 ? LDS_NODES : 1];                       \
+    extern __shared__ uint32_t s_dyn[];
 
 // ------------------------------------------------------------------ textures (texture.rs)
 __device__ __forceinline__ float perlin_noise(const float4 *vec, const int *perm, V3 p) {
@@ -678,12 +773,11 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Queue q, const DCamera *camp
     if (lane == 0) q.count[chunk] = have + n;
 }
 
-template <bool FLAT>
+template <int ACCEL>
 __global__ void __launch_bounds__(BLOCK) k_extend(Queue q, const DScene *scp, uint32_t k0, uint32_t k1, uint32_t has_media) {
     SceneRef sc = *as_uniform(scp);
-    __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
-    __shared__ rt_node s_nodes[FLAT ? 1 : LDS_NODES];
-    if (!FLAT) { // stage the top of the BVH
+    RT_ACCEL_LDS(ACCEL)
+    if (ACCEL == ACCEL_BVH2) { // stage the top of the BVH
         const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
         const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
         float4 *dst = reinterpret_cast<float4 *>(s_nodes);
@@ -709,10 +803,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend(Queue q, const DScene *scp, ui
             rc.bounce = sb.y;
         }
         Best best;
-        if (FLAT)
-            scan_flat(sc, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
-        else
-            traverse<true>(sc, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack + threadIdx.x, s_nodes, best);
+        closest_hit<ACCEL, true>(sc, o, d, ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack, s_nodes, s_dyn, best);
         q.hit[s] = make_float4(best.t, bitsf(best.ref), best.u, best.v);
     }
 }
@@ -954,14 +1045,13 @@ __device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
 
 // Registers are held to 128 per lane (4 waves per SIMD): measured faster than 3 waves with no
 // spills or 5 with more, on every workload.
-template <int MODE, bool FLAT>
+template <int MODE, int ACCEL>
 __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
                                                   uint32_t has_media, uint32_t grab, uint32_t refill_min) {
     SceneRef sc = *as_uniform(scp);
     CamRef cam = *as_uniform(camp);
-    __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
-    __shared__ rt_node s_nodes[FLAT ? 1 : LDS_NODES];
-    if (!FLAT) {
+    RT_ACCEL_LDS(ACCEL)
+    if (ACCEL == ACCEL_BVH2) {
         const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
         const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
         float4 *dst = reinterpret_cast<float4 *>(s_nodes);
@@ -989,11 +1079,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         if (alive) {
             RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
             Best best;
-            if (FLAT)
-                scan_flat(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
-            else
-                traverse<true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack + threadIdx.x, s_nodes,
-                               best);
+            closest_hit<ACCEL, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack, s_nodes, s_dyn, best);
             scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
                                  best.mat, sf);
         }
@@ -1059,13 +1145,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
 }
 
 // ------------------------------------------------------------------ hooks
-template <bool FLAT>
+template <int ACCEL>
 __global__ void __launch_bounds__(BLOCK) k_intersect_batch(const DScene *scp, uint32_t n, const float *o3, const float *d3,
                                                             const float *time, const uint32_t *origin_ref, float tmin, float tmax,
                                                             int *hit,
                                                             int *prim, float *t, float *u, float *v) {
     SceneRef sc = *as_uniform(scp);
-    __shared__ uint32_t s_stack[FLAT ? 1 : STACK_DEPTH * BLOCK];
+    RT_ACCEL_LDS(ACCEL)
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     V3 o = {o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d = {d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
@@ -1073,10 +1159,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(const DScene *scp, ui
     RayCtx rc{0u, 0u, i, 0u, 0u};
     const uint32_t from = origin_ref ? origin_ref[i] : RT_REF_NONE;
     Best best;
-    if (FLAT)
-        scan_flat(sc, o, d, tm, tmin, tmax, from, rc, best);
-    else
-        traverse<false>(sc, o, d, tm, tmin, tmax, from, rc, s_stack + threadIdx.x, nullptr, best);
+    closest_hit<ACCEL, false>(sc, o, d, tm, tmin, tmax, from, rc, s_stack, s_nodes, s_dyn, best);
     int pid = -1;
     float uu = best.u, vv = best.v;
     if (best.ref != RT_REF_NONE) {

@@ -21,13 +21,17 @@ dev = ra.Device(0)
 dev.upload(sb)
 rc = cam.build()
 dev.film_resize(cam.image_width, cam.image_height)
-variants = [dict(wavefront=True)]
-for wps in (4,):
-    for rm in (8,):
-        variants.append(dict(refill_min=rm, waves_per_simd=wps))
 dev.render(rc, mode=mode, seed=1)
-for v in variants:
-    t0 = time.perf_counter()
-    st = dev.render(rc, mode=mode, seed=2, **v)
-    dt = time.perf_counter() - t0
-    print(f"{name} {v}: {st.segments / dt / 1e6:9.1f} Mrays/s  {dt * 1e3:8.2f} ms  segs={st.segments}", flush=True)
+for accel in (("reference", 4), ("sah", 4), ("reference", 2)):
+    dev.set_accel(*accel)
+    dev.upload(sb)
+    info = dev.accel_info()
+    for v in (dict(wavefront=True), dict()):
+        dev.render(rc, mode=mode, seed=2, **v)
+        t0 = time.perf_counter()
+        st = dev.render(rc, mode=mode, seed=2, **v)
+        dt = time.perf_counter() - t0
+        print(f"{name} {info['kind']} {accel[0]:9s} {'wavefront ' if v else 'persistent'}: {st.segments / dt / 1e6:9.1f} Mrays/s"
+              f"  {dt * 1e3:8.2f} ms  segs={st.segments} nodes={info['nodes']} stack={info['stack_entries']}", flush=True)
+    if info["kind"] == "flat":
+        break
