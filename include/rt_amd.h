@@ -201,18 +201,21 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *scene);
 /* Acceleration structure built by the next rt_upload_scene.  The descriptor always carries the
  * reference's own grouping (BVHNode::new topology, boundingbox.rs:179-206, and HittableVec
  * lists); the closest hit does not depend on the grouping, so the device may regroup:
- *   width 4 (default): binary nodes and lists collapsed into 4-wide nodes with boxes recomputed
+ *   width 4 (default, with RT_BUILD_AUTO): binary nodes and lists collapsed into 4-wide nodes with boxes recomputed
  *           from the fp32 primitives; builder RT_BUILD_REFERENCE keeps the descriptor's
- *           grouping, RT_BUILD_SAH regroups all primitives by a binned surface-area heuristic;
+ *           grouping, RT_BUILD_SAH regroups all primitives by a binned surface-area heuristic,
+ *           RT_BUILD_AUTO builds both and keeps the cheaper by surface-area cost;
  *   width 2: the descriptor's nodes traversed as they are (near child first).
  * A world that is one short list of primitives is scanned without any tree either way. */
 #define RT_BUILD_REFERENCE 0u
 #define RT_BUILD_SAH 1u
+#define RT_BUILD_AUTO 2u /* both, keep the lower surface-area cost */
 int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width);
 typedef struct {
     uint32_t kind;          /* 0 = flat list scan, 1 = binary nodes, 2 = 4-wide nodes */
     uint32_t nodes, depth;  /* of the structure searched (depth: wide only) */
     uint32_t stack_entries; /* per-lane traversal stack held in LDS */
+    double cost;            /* wide only: expected box tests of a random ray through the root box */
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 

@@ -84,10 +84,10 @@ RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
 
 
 class RtAccelInfo(C.Structure):
-    _fields_ = [("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32)]
+    _fields_ = [("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32), ("cost", f64)]
 
 
-RT_BUILD_REFERENCE, RT_BUILD_SAH = 0, 1
+RT_BUILD_REFERENCE, RT_BUILD_SAH, RT_BUILD_AUTO = 0, 1, 2
 RT_FLAG_TIME_KERNELS = 1
 RT_FLAG_WAVEFRONT = 2
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3

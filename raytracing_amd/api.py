@@ -270,15 +270,15 @@ class Device:
     def set_stream(self, hip_stream_ptr):
         self._check(self.lib.rt_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "rt_set_stream")
 
-    def set_accel(self, builder="reference", width=4):
-        """Structure built by the next upload: builder "reference" | "sah", width 2 | 4."""
-        b = {"reference": _ffi.RT_BUILD_REFERENCE, "sah": _ffi.RT_BUILD_SAH}[builder]
+    def set_accel(self, builder="auto", width=4):
+        """Structure built by the next upload: builder "reference" | "sah" | "auto", width 2 | 4."""
+        b = {"reference": _ffi.RT_BUILD_REFERENCE, "sah": _ffi.RT_BUILD_SAH, "auto": _ffi.RT_BUILD_AUTO}[builder]
         self._check(self.lib.rt_set_accel(self.h, b, width), "rt_set_accel")
 
     def accel_info(self):
         a = _ffi.RtAccelInfo()
         self._check(self.lib.rt_get_accel_info(self.h, C.byref(a)), "rt_get_accel_info")
-        return dict(kind=("flat", "bvh2", "bvh4")[a.kind], nodes=a.nodes, depth=a.depth, stack_entries=a.stack_entries)
+        return dict(kind=("flat", "bvh2", "bvh4")[a.kind], nodes=a.nodes, depth=a.depth, stack_entries=a.stack_entries, cost=a.cost)
 
     def upload(self, scene: SceneBuilder):
         desc = scene.flatten()

@@ -84,6 +84,9 @@ struct Inner {
 
 struct Stats {
     uint32_t nodes = 0, depth = 0, stack_need = 0, leaves = 0;
+    // surface-area cost: expected boxes tested by a random ray that enters the root box =
+    // 4 * sum over nodes of area(node) / area(root)
+    double cost = 0.0;
 };
 
 struct Builder {
@@ -342,22 +345,56 @@ inline uint32_t stack_need(const std::vector<Node4> &nodes) {
     return nodes.empty() ? 0 : need[0] + 1;
 }
 
+inline double sa_cost(const std::vector<Node4> &nodes) {
+    if (nodes.empty()) return 0.0;
+    auto child_area = [&](const Node4 &n, int k) {
+        Box b;
+        for (int a = 0; a < 3; ++a) b.lo[a] = n.lo[a][k], b.hi[a] = n.hi[a][k];
+        return b.area();
+    };
+    Box rootb;
+    for (int k = 0; k < 4; ++k)
+        if (nodes[0].child[k] != RT_REF_NONE) {
+            Box b;
+            for (int a = 0; a < 3; ++a) b.lo[a] = nodes[0].lo[a][k], b.hi[a] = nodes[0].hi[a][k];
+            rootb.add(b);
+        }
+    const double ra = rootb.area();
+    if (!(ra > 0.0)) return 0.0;
+    double sum = ra; // the root itself is always visited
+    for (const Node4 &n : nodes)
+        for (int k = 0; k < 4; ++k)
+            if (n.child[k] != RT_REF_NONE && (n.child[k] >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) sum += child_area(n, k);
+    return 4.0 * sum / ra;
+}
+
 // Builds the wide BVH of the (validated) scene.  builder: RT_BUILD_REFERENCE keeps the grouping
-// of the descriptor's binary nodes, RT_BUILD_SAH regroups all primitives.  Returns "" or an error.
+// of the descriptor's binary nodes, RT_BUILD_SAH regroups all primitives, RT_BUILD_AUTO builds both
+// and keeps the one with the lower surface-area cost.  Returns "" or an error.
 inline std::string build_wide_bvh(const rt_scene_desc *s, uint32_t builder, std::vector<Node4> &nodes, uint32_t &root,
                                   Stats &st) {
     Builder b(s);
     b.slots.reserve(size_t(s->n_quads + s->n_spheres + s->n_media) * 2 + 16);
-    int32_t top = b.from_ref(s->root, 0);
+    const int32_t top = b.from_ref(s->root, 0);
     if (top < 0) return b.error;
-    if (builder == RT_BUILD_SAH && b.slots[top].node >= 0) {
+    auto finish = [&](int32_t t, std::vector<Node4> &out, Stats &o) {
+        o = Stats();
+        root = b.collapse(t, out, o);
+        o.stack_need = stack_need(out);
+        o.cost = sa_cost(out);
+    };
+    if (builder != RT_BUILD_SAH) finish(top, nodes, st);
+    if (builder != RT_BUILD_REFERENCE && b.slots[top].node >= 0) {
         std::vector<int32_t> prims;
         b.collect_prims(top, prims);
-        top = b.sah_tree(prims, 0, prims.size());
+        const int32_t sah_top = b.sah_tree(prims, 0, prims.size());
+        std::vector<Node4> alt;
+        Stats alt_st;
+        finish(sah_top, alt, alt_st);
+        if (builder == RT_BUILD_SAH || alt_st.cost < st.cost) nodes.swap(alt), st = alt_st;
+    } else if (builder == RT_BUILD_SAH) {
+        finish(top, nodes, st);
     }
-    st = Stats();
-    root = b.collapse(top, nodes, st);
-    st.stack_need = stack_need(nodes);
     return "";
 }
 

@@ -36,7 +36,7 @@ struct rt_handle {
     bool have_scene = false;
     bool flat = false;
     int accel = ACCEL_BVH2;                 // structure the kernels search for this scene
-    uint32_t build = RT_BUILD_REFERENCE, width = 4; // rt_set_accel: applies to the next upload
+    uint32_t build = RT_BUILD_AUTO, width = 4; // rt_set_accel: applies to the next upload
     uint32_t stack4 = 0;                    // LDS stack entries per lane of the wide traversal
     accel::Stats accel_stats{};
     uint32_t has_media = 0, n_prims = 0;
@@ -514,8 +514,9 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
         uint32_t root4 = 0;
         std::string err = accel::build_wide_bvh(s, h->build, nodes4, root4, h->accel_stats);
         if (!err.empty()) return fail(h, "rt_upload_scene: " + err);
-        // one LDS column per lane: 160 KB per CU / 1024 lanes at 4 waves per SIMD = 40 entries
-        if (h->accel_stats.stack_need <= 40) {
+        // one LDS column per lane, 1 KB per entry per block: up to 40 entries leave 4 blocks per CU
+        // (160 KB of LDS), deeper trees run at lower occupancy, 64 entries is the 64 KB block limit
+        if (h->accel_stats.stack_need <= 64) {
             h->accel = ACCEL_BVH4;
             h->stack4 = std::max(8u, (h->accel_stats.stack_need + 3u) & ~3u);
         } else {
@@ -574,7 +575,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
 
 int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width) {
     if (!h) return -1;
-    if (builder > RT_BUILD_SAH) return fail(h, "rt_set_accel: unknown builder");
+    if (builder > RT_BUILD_AUTO) return fail(h, "rt_set_accel: unknown builder");
     if (width != 2 && width != 4) return fail(h, "rt_set_accel: width must be 2 or 4");
     if (width == 2 && builder != RT_BUILD_REFERENCE)
         return fail(h, "rt_set_accel: the binary traversal walks the descriptor's own nodes; regrouping needs width 4");
@@ -590,6 +591,7 @@ int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     out->nodes = h->accel == ACCEL_BVH4 ? h->accel_stats.nodes : (h->accel == ACCEL_BVH2 ? h->sc.n_nodes : 0u);
     out->depth = h->accel == ACCEL_BVH4 ? h->accel_stats.depth : 0u;
     out->stack_entries = h->accel == ACCEL_BVH4 ? h->stack4 : (h->accel == ACCEL_BVH2 ? uint32_t(STACK_DEPTH) : 0u);
+    out->cost = h->accel == ACCEL_BVH4 ? h->accel_stats.cost : 0.0;
     return 0;
 }
 

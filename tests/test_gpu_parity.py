@@ -143,7 +143,7 @@ def test_acceleration_structures_agree(device, name):
             infos.append(device.accel_info())
             results.append(device.intersect_batch(o, d, tm, origin_prim=frm))
     finally:
-        device.set_accel("reference", 4)
+        device.set_accel("auto", 4)
     assert [i["kind"] for i in infos] == ["bvh4", "bvh4", "bvh2"], infos
     assert infos[0]["stack_entries"] <= 40 and infos[0]["nodes"] < infos[2]["nodes"]
     hit0, prim0, t0, u0, v0 = results[2]
@@ -174,7 +174,7 @@ def test_render_with_other_acceleration_structures(device, name, builder, width)
         device.render(rc, mode=mode, seed=3)
         img = device.film().astype(np.float64)
     finally:
-        device.set_accel("reference", 4)
+        device.set_accel("auto", 4)
     off = ~np.isclose(img, base, rtol=2e-5, atol=1e-5)
     assert off.mean() < 0.01, off.mean()  # ties and separately compiled kernels fork a few paths
 
@@ -419,7 +419,7 @@ def test_upload_validation_rejects_bad_descriptors(device):
         with pytest.raises(ra.RtError, match="deeper traversal stack"):
             device.upload_desc(bdesc)
     finally:
-        device.set_accel("reference", 4)
+        device.set_accel("auto", 4)
     device.upload_desc(bdesc)
     with pytest.raises(ra.RtError, match="width"):
         device.set_accel("reference", 3)

@@ -24,7 +24,9 @@ dev.film_resize(cam.image_width, cam.image_height)
 dev.render(rc, mode=mode, seed=1)
 for accel in (("reference", 4), ("sah", 4), ("reference", 2)):
     dev.set_accel(*accel)
+    t_up = time.perf_counter()
     dev.upload(sb)
+    t_up = time.perf_counter() - t_up
     info = dev.accel_info()
     for v in (dict(wavefront=True), dict()):
         dev.render(rc, mode=mode, seed=2, **v)
@@ -32,6 +34,6 @@ for accel in (("reference", 4), ("sah", 4), ("reference", 2)):
         st = dev.render(rc, mode=mode, seed=2, **v)
         dt = time.perf_counter() - t0
         print(f"{name} {info['kind']} {accel[0]:9s} {'wavefront ' if v else 'persistent'}: {st.segments / dt / 1e6:9.1f} Mrays/s"
-              f"  {dt * 1e3:8.2f} ms  segs={st.segments} nodes={info['nodes']} stack={info['stack_entries']}", flush=True)
+              f"  {dt * 1e3:8.2f} ms  segs={st.segments} nodes={info['nodes']} stack={info['stack_entries']} cost={info['cost']:.1f} upload={t_up * 1e3:.0f}ms", flush=True)
     if info["kind"] == "flat":
         break
