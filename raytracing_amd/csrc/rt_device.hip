@@ -516,7 +516,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
         if (!err.empty()) return fail(h, "rt_upload_scene: " + err);
         // one LDS column per lane, 1 KB per entry per block: up to 40 entries leave 4 blocks per CU
         // (160 KB of LDS), deeper trees run at lower occupancy, 64 entries is the 64 KB block limit
-        if (h->accel_stats.stack_need <= 64) {
+        if (h->accel_stats.stack_need <= 64 && nodes4.size() < (1u << 25)) { // byte offsets of nodes stay 32-bit
             h->accel = ACCEL_BVH4;
             h->stack4 = std::max(8u, (h->accel_stats.stack_need + 3u) & ~3u);
         } else {

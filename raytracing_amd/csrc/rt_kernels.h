@@ -386,27 +386,43 @@ __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, f
     best.t = thi;
     best.ref = best.mat = RT_REF_NONE;
     best.u = best.v = 0.f;
-    const V3 inv = {rcp(d.x), rcp(d.y), rcp(d.z)};
-    const float4 *nodes = sc.nodes4;
+    typedef float v2f __attribute__((ext_vector_type(2))); // two children per packed instruction
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const v2f ix = {rcp(d.x), rcp(d.x)}, iy = {rcp(d.y), rcp(d.y)}, iz = {rcp(d.z), rcp(d.z)};
+    // The plane a ray meets first on each axis follows from the sign of its direction, so the
+    // near and far planes are chosen by the load address (lo at float4 0..2, hi at 3..5) and no
+    // per-axis min/max is needed.  Sign bit, not `< 0`: -0 has reciprocal -inf.
+    const uint32_t nx = (fbits(d.x) >> 31) * 48u, ny = 16u + (fbits(d.y) >> 31) * 48u, nz = 32u + (fbits(d.z) >> 31) * 48u;
+    const uint32_t fx = 48u - nx, fy = 80u - ny, fz = 112u - nz; // the other plane of each axis
+    const char *nodes = reinterpret_cast<const char *>(sc.nodes4);
+    auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(nodes + byte_off); };
     uint32_t sp = 0;
     uint32_t cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
     for (;;) {
         while ((cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) {
-            const float4 *n = nodes + 8 * size_t(cur & RT_REF_INDEX_MASK);
-            const float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], cf = n[6];
-            const float lo_x[4] = {lx.x, lx.y, lx.z, lx.w}, lo_y[4] = {ly.x, ly.y, ly.z, ly.w}, lo_z[4] = {lz.x, lz.y, lz.z, lz.w};
-            const float hi_x[4] = {hx.x, hx.y, hx.z, hx.w}, hi_y[4] = {hy.x, hy.y, hy.z, hy.w}, hi_z[4] = {hz.x, hz.y, hz.z, hz.w};
+            const uint32_t nb = (cur & RT_REF_INDEX_MASK) * 128u; // the wide array stays below 4 GiB (checked at upload)
+            const float4 ax = ld(nb + nx), ay = ld(nb + ny), az = ld(nb + nz);
+            const float4 bx = ld(nb + fx), by = ld(nb + fy), bz = ld(nb + fz);
+            const float4 cf = ld(nb + 96u);
             uint32_t ref[4] = {fbits(cf.x), fbits(cf.y), fbits(cf.z), fbits(cf.w)};
+            // BoundingBox3::hit (boundingbox.rs:96-113) for four boxes; see hit_box for the slack.
+            // 0 * inf = NaN where the origin lies on a plane the ray is parallel to: max3/min3
+            // drop NaN operands, which leaves that axis unconstrained.
+            const v2f nx01 = (v2f{ax.x, ax.y} - ox) * ix, nx23 = (v2f{ax.z, ax.w} - ox) * ix;
+            const v2f ny01 = (v2f{ay.x, ay.y} - oy) * iy, ny23 = (v2f{ay.z, ay.w} - oy) * iy;
+            const v2f nz01 = (v2f{az.x, az.y} - oz) * iz, nz23 = (v2f{az.z, az.w} - oz) * iz;
+            const v2f fx01 = (v2f{bx.x, bx.y} - ox) * ix, fx23 = (v2f{bx.z, bx.w} - ox) * ix;
+            const v2f fy01 = (v2f{by.x, by.y} - oy) * iy, fy23 = (v2f{by.z, by.w} - oy) * iy;
+            const v2f fz01 = (v2f{bz.x, bz.y} - oz) * iz, fz23 = (v2f{bz.z, bz.w} - oz) * iz;
+            const float tn[4] = {fmaxf(fmaxf(fmaxf(nx01.x, ny01.x), nz01.x), tlo), fmaxf(fmaxf(fmaxf(nx01.y, ny01.y), nz01.y), tlo),
+                                 fmaxf(fmaxf(fmaxf(nx23.x, ny23.x), nz23.x), tlo), fmaxf(fmaxf(fmaxf(nx23.y, ny23.y), nz23.y), tlo)};
+            const float tf[4] = {fminf(fminf(fminf(fx01.x, fy01.x), fz01.x), best.t), fminf(fminf(fminf(fx01.y, fy01.y), fz01.y), best.t),
+                                 fminf(fminf(fminf(fx23.x, fy23.x), fz23.x), best.t), fminf(fminf(fminf(fx23.y, fy23.y), fz23.y), best.t)};
             uint32_t key[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { // BoundingBox3::hit (boundingbox.rs:96-113), see hit_box
-                const float x0 = (lo_x[i] - o.x) * inv.x, x1 = (hi_x[i] - o.x) * inv.x;
-                const float y0 = (lo_y[i] - o.y) * inv.y, y1 = (hi_y[i] - o.y) * inv.y;
-                const float z0 = (lo_z[i] - o.z) * inv.z, z1 = (hi_z[i] - o.z) * inv.z;
-                const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tlo));
-                const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), best.t));
-                const bool hit = (tn <= fmaf(fabsf(tf), BOX_SLACK, tf)) & (ref[i] != RT_REF_NONE);
-                key[i] = hit ? fbits(tn) : 0xFFFFFFFFu; // tn >= tlo > 0: float order = unsigned order
+            for (int i = 0; i < 4; ++i) {
+                const bool hit = (tn[i] <= fmaf(fabsf(tf[i]), BOX_SLACK, tf[i])) & (ref[i] != RT_REF_NONE);
+                key[i] = hit ? fbits(tn[i]) : 0xFFFFFFFFu; // tn >= tlo > 0: float order = unsigned order
             }
             // sort the four (key, ref) pairs ascending: 5 compare-exchanges
 #define RT_CSWAP(a, b)                                                                       \
@@ -1044,7 +1060,7 @@ __device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
 }
 
 // Registers are held to 128 per lane (4 waves per SIMD): measured faster than 3 waves with no
-// spills or 5 with more, on every workload.
+// spills or 5, 6, 8 with more, on every workload, flat and BVH.
 template <int MODE, int ACCEL>
 __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
                                                   uint32_t has_media, uint32_t grab, uint32_t refill_min) {
