@@ -313,6 +313,14 @@ int rth_prim_count(rth_scene *);
  * textures / materials / objects to the scene and returns the object id of the world
  * HittableVec (>= 0), or < 0 with the message in rth_last_error. */
 int rth_load_toml(rth_scene *, const char *toml_text);
+/* A scene file: the same format extended to a whole render -- a [camera] table with the
+ * CameraBuilder fields (camera.rs:134-171), [r, g, b] colours, Box / ConstantMedium / Group
+ * objects, center_vec, rotate_y / translate, `light = true` (see raytracing_amd/host/config.cpp).
+ * Sets the scene's world and lights (the two arguments of Camera::render, camera.rs:368); image
+ * paths are relative to base_dir.  camera receives the builder settings (defaults where the file
+ * is silent), has_camera whether the file has a [camera] table.  Returns the world's object id. */
+int rth_load_scene_toml(rth_scene *, const char *toml_text, const char *base_dir, rth_camera_builder *camera,
+                        int *has_camera);
 int rth_list_add(rth_scene *, int list, int obj); /* HittableVec::add, hittable.rs:238-244 */
 int rth_material_by_name(rth_scene *, const char *name); /* materials loaded from TOML */
 

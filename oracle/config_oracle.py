@@ -195,3 +195,167 @@ def load(sb, text):
 
 def toml_objects(sb, text):
     return load(sb, text)[0]
+
+
+# ---------------------------------------------------------------------------- scene files
+def color_ext(v, key):
+    """Scene files also take [r, g, b] floats."""
+    if isinstance(v, list):
+        if len(v) != 3 or not all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in v):
+            raise ConfigError(f"{key} must be a hex code, a number or [r, g, b].")
+        return tuple(float(x) for x in v)
+    return parse_color(v, key)
+
+
+def load_scene(sb, text, base_dir=""):
+    """The scene-file superset of the reference's format (camera table, float colours, noise
+    textures, Box / ConstantMedium / Group objects, center_vec, rotate_y / translate, light
+    flags), restated for the oracle's builder.  Sets world and lights on `sb`; returns the
+    camera fields of the [camera] table as a dict (None without one).  Primitives are created
+    in file order, so their ids equal those the product's loader assigns."""
+    import math
+    from pathlib import Path
+
+    import numpy as np
+
+    cfg = tomli.loads(text)
+    textures, materials, named, lights = {}, {}, {}, []
+    for name in sorted(cfg.get("textures", {})):
+        t = cfg["textures"][name]
+        base = f"config.textures.{name}"
+        T = str(t.get("type", "")).upper()
+        if T in ("COLOR", "SOLIDCOLOR", "SOLID_COLOR"):
+            textures[name] = sb.tex_solid(*color_ext(require(t, "color", base), base + ".color"))
+        elif T in ("CHECKERBOARD", "CHECKER"):
+            sub = []
+            for k, e in enumerate(require(t, "textures", base)):
+                sub.append(textures[e] if isinstance(e, str) and e in textures
+                           else sb.tex_solid(*color_ext(e, f"{base}.textures.{k}")))
+            if len(sub) != 2:
+                raise ConfigError(f"{base}.textures must be an array of length 2.")
+            textures[name] = sb.tex_checker(floatlike(require(t, "scale", base), base + ".scale"), sub[0], sub[1])
+        elif T == "IMAGE":
+            from PIL import Image
+            p = Path(require(t, "path", base))
+            im = Image.open(p if p.is_absolute() or not base_dir else Path(base_dir) / p)
+            if im.mode != "RGB":
+                raise ConfigError("Must be 8-bit PNG.")
+            textures[name] = sb.tex_image(np.asarray(im))
+        elif T in ("NOISE", "PERLIN"):
+            rv = np.asarray(require(t, "ranvec", base), dtype=np.float64)
+            pm = np.asarray(require(t, "perm", base), dtype=np.int32)
+            if rv.shape != (256, 3) or pm.shape != (3, 256):
+                raise ConfigError(f"{base}: ranvec must hold 256 vectors and perm 3 permutations.")
+            textures[name] = sb.tex_noise(floatlike(require(t, "scale", base), base + ".scale"), rv, pm)
+        else:
+            raise ConfigError(f"{base}.type must be a valid texture type.")
+
+    def tex_or_color(t, base):
+        if "texture" in t:
+            if t["texture"] not in textures:
+                raise ConfigError(f"{base}.texture does not describe a valid texture.")
+            return textures[t["texture"]]
+        return sb.tex_solid(*color_ext(require(t, "color", base), base + ".color"))
+
+    for name in sorted(cfg.get("materials", {})):
+        t = cfg["materials"][name]
+        base = f"config.materials.{name}"
+        T = str(t.get("type", "")).upper()
+        if T == "LAMBERTIAN":
+            materials[name] = sb.lambertian(tex_or_color(t, base))
+        elif T in ("METAL", "METALLIC", "FUZZY"):
+            fuzz = floatlike(require(t, "fuzz", base), base + ".fuzz")
+            materials[name] = sb.metal(color_ext(require(t, "albedo", base), base + ".albedo"), fuzz / 100.0 if fuzz > 1.0 else fuzz)
+        elif T in ("LIGHT", "LIGHTSOURCE", "DIFFUSELIGHT"):
+            materials[name] = sb.light(tex_or_color(t, base))
+        elif T == "DIELECTRIC":
+            materials[name] = sb.dielectric(floatlike(require(t, "refractive_index", base), base + ".refractive_index"))
+        elif T == "ISOTROPIC":
+            materials[name] = sb.isotropic(tex_or_color(t, base))
+        elif T == "SOLIDCOLOR":
+            materials[name] = sb.lambertian(sb.tex_solid(*color_ext(require(t, "color", base), base + ".color")))
+        elif T == "COLOREDLIGHT":
+            c = color_ext(require(t, "color", base), base + ".color")
+            k = floatlike(t["brightness"], base + ".brightness") if "brightness" in t else 1.0
+            materials[name] = sb.light(sb.tex_solid(*(x * k for x in c)))
+        else:
+            raise ConfigError(f"{base}.type must be a valid material type.")
+
+    def mat(t, base):
+        m = require(t, "material", base)
+        if m not in materials:
+            raise ConfigError(f"{base}.material does not describe a valid texture.")
+        return materials[m]
+
+    def obj_value(v, base):
+        if isinstance(v, str):
+            if v not in named:
+                raise ConfigError(f"{base} names an object that has not been listed ({v}).")
+            return named[v]
+        return obj(v, base)
+
+    def obj(t, base):
+        T = str(t.get("type", "")).upper()
+        if T == "SPHERE":
+            o = sb.sphere(vec3(require(t, "center", base), base + ".center"), floatlike(require(t, "radius", base), base + ".radius"),
+                          mat(t, base), center_vec=vec3(t["center_vec"], base + ".center_vec") if "center_vec" in t else (0.0, 0.0, 0.0))
+        elif T == "PARALLELOGRAM":
+            vs = require(t, "vectors", base)
+            o = sb.quad(vec3(require(t, "corner", base), base + ".corner"), vec3(vs[0], base + ".vectors.0"),
+                        vec3(vs[1], base + ".vectors.1"), mat(t, base))
+        elif T == "DISC":
+            c, vs = vec3(require(t, "center", base), base + ".center"), require(t, "vectors", base)
+            u, v = vec3(vs[0], base + ".vectors.0"), vec3(vs[1], base + ".vectors.1")
+            o = sb.quad(tuple(c[k] - u[k] - v[k] for k in range(3)), tuple(2 * x for x in u), tuple(2 * x for x in v), mat(t, base), shape=2)
+        elif T == "TRIANGLE":
+            p = [vec3(x, f"{base}.points.{k}") for k, x in enumerate(require(t, "points", base))]
+            o = sb.quad(p[0], tuple(p[1][k] - p[0][k] for k in range(3)), tuple(p[2][k] - p[0][k] for k in range(3)), mat(t, base), shape=1)
+        elif T == "BOX":
+            o = sb.box3(vec3(require(t, "min", base), base + ".min"), vec3(require(t, "max", base), base + ".max"), mat(t, base))
+        elif T in ("CONSTANTMEDIUM", "MEDIUM"):
+            boundary = obj_value(require(t, "boundary", base), base + ".boundary")
+            o = sb.medium(boundary, floatlike(require(t, "density", base), base + ".density"), tex_or_color(t, base))
+        elif T == "GROUP":
+            kids = [obj_value(c, f"{base}.children.{k}") for k, c in enumerate(require(t, "children", base))]
+            o = sb.bvh(kids) if t.get("bvh", False) else sb.list(kids)
+        else:
+            raise ConfigError(f"{base}.type must be a valid object type.")
+        if "rotate_y" in t:
+            o = sb.rotate_y(o, floatlike(t["rotate_y"], base + ".rotate_y"))
+        if "translate" in t:
+            o = sb.translate(o, vec3(t["translate"], base + ".translate"))
+        if t.get("light", False):
+            lights.append(o)
+        if "name" in t:
+            named[t["name"]] = o
+        return o
+
+    world = sb.list([obj(t, f"config.objects.{i}") for i, t in enumerate(cfg.get("objects", []))])
+    sb.set_world(world)
+    if len(lights) == 1 and not cfg.get("light_list", False):
+        sb.set_lights(lights[0])
+    elif lights:
+        sb.set_lights(sb.list(lights))
+    else:
+        sb.set_lights(None)
+    c = cfg.get("camera")
+    if c is None:
+        return None
+    cam = dict(image_width=400, image_height=200, vfov=90.0, samples_per_px=10, max_depth=10, background=None,
+               camera_center=(0.0, 0.0, 0.0), camera_target=(0.0, 0.0, -1.0), vup=(0.0, 1.0, 0.0), defocus_angle=0.0,
+               focal_length=1.0)  # camera.rs:183-202
+    for k in ("image_width", "image_height", "samples_per_px", "max_depth"):
+        if k in c:
+            cam[k] = int(c[k])
+    if "aspect_ratio" in c:  # camera.rs:78-92
+        cam["image_height"] = int(math.floor(cam["image_width"] / float(c["aspect_ratio"]) + 0.5))
+    for k in ("vfov", "defocus_angle", "focal_length"):
+        if k in c:
+            cam[k] = float(c[k])
+    for k in ("camera_center", "camera_target", "vup"):
+        if k in c:
+            cam[k] = vec3(c[k], f"config.camera.{k}")
+    if "background" in c:
+        b = c["background"]
+        cam["background"] = None if isinstance(b, str) and b.upper() == "SKY" else color_ext(b, "config.camera.background")
+    return cam

@@ -147,6 +147,7 @@ SIGNATURES = {
     "rth_set_lights": (C.c_int, [_vp, C.c_int]),
     "rth_prim_count": (C.c_int, [_vp]),
     "rth_load_toml": (C.c_int, [_vp, C.c_char_p]),
+    "rth_load_scene_toml": (C.c_int, [_vp, C.c_char_p, C.c_char_p, P(CameraBuilderStruct), P(C.c_int)]),
     "rth_list_add": (C.c_int, [_vp, C.c_int, C.c_int]),
     "rth_material_by_name": (C.c_int, [_vp, C.c_char_p]),
     "rth_flatten": (C.c_int, [_vp, P(P(RtSceneDesc))]),

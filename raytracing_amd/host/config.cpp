@@ -8,6 +8,15 @@
 // Beyond config.rs: the `Image` texture, and `Disc` / `Triangle` objects are built here (the
 // reference parses them and then hits todo!() at config.rs:385, :617-622; `Triangle` has no
 // parse arm at all).
+//
+// load_scene_file() reads a superset of that format which can describe a whole render, so that
+// a workload is a data file: a [camera] table with the CameraBuilder fields (camera.rs:134-171),
+// colours as [r, g, b] floats, `noise` textures with explicit tables, checkerboards over named
+// textures, and for objects: `Box` (box3, hittable.rs:398-455), `ConstantMedium` with an inline
+// boundary, `Group` (a HittableVec, or a BVHNode with bvh = true) with inline children,
+// `center2` on a sphere (moving centre), `rotate_y` / `translate` on any object (applied in that
+// order, as main.rs:45-48 does) and `light = true` to put an object into the `lights` argument
+// of Camera::render.
 #include "raytracing.hpp"
 
 #include <cctype>
@@ -376,6 +385,20 @@ Color parse_color(const Value &v, const std::string &key) { // config.rs:132-145
     }
     throw Error(key + " must be a hex code or number.");
 }
+// scene files also take [r, g, b] floats: emission 20 * white or random albedos are not 8-bit
+Color parse_color_ext(const Value &v, const std::string &key) {
+    if (v.type == Value::ARRAY && !v.array_of_tables) {
+        if (v.arr.size() != 3) throw Error(key + " must be a hex code, a number or [r, g, b].");
+        double c[3];
+        for (int i = 0; i < 3; ++i) {
+            if (v.arr[i].type == Value::FLOAT) c[i] = v.arr[i].f;
+            else if (v.arr[i].type == Value::INTEGER) c[i] = double(v.arr[i].i);
+            else throw Error(key + "." + std::to_string(i) + " must be a decimal number.");
+        }
+        return Color{c[0], c[1], c[2]};
+    }
+    return parse_color(v, key);
+}
 double parse_floatlike(const Value &v, const std::string &key) { // config.rs:147-156
     if (v.type == Value::FLOAT) return v.f;
     if (v.type == Value::INTEGER) return double(v.i);
@@ -407,6 +430,22 @@ const std::string *get_type(const Table &t) {
 struct Loader {
     std::map<std::string, TexturePtr> textures;
     std::map<std::string, MaterialPtr> materials;
+    bool extended = false;      // scene-file superset
+    std::string base_dir;       // image paths of a scene file are relative to it
+    int *next_prim_id = nullptr; // primitives are numbered in the order they are created
+    std::vector<HittablePtr> lights;
+
+    Color color(const Value &v, const std::string &key) const { return extended ? parse_color_ext(v, key) : parse_color(v, key); }
+    template <typename T> std::shared_ptr<T> numbered(std::shared_ptr<T> h) {
+        if (next_prim_id) h->prim_id = (*next_prim_id)++;
+        return h;
+    }
+    // a material given by name, or (scene files) a texture given by name or an inline colour
+    TexturePtr texture_or_color(const Table &t, const std::string &base) {
+        auto it = t.find("texture");
+        if (it != t.end()) return texture_by_name(it->second, base + ".texture");
+        return std::make_shared<SolidColor>(color(require_value(t, "color", base), base + ".color"));
+    }
 
     TexturePtr texture_by_name(const Value &v, const std::string &key) { // config.rs:228-247
         if (v.type != Value::STRING) throw Error(key + " must be a string representing a previously listed texture.");
@@ -429,20 +468,54 @@ struct Loader {
         if (!ty) throw Error(base + ".type must be a string.");
         std::string T = upper(*ty);
         if (T == "COLOR" || T == "SOLIDCOLOR" || T == "SOLID_COLOR") {
-            return std::make_shared<SolidColor>(parse_color(require_value(t, "color", base), base + ".color"));
+            return std::make_shared<SolidColor>(color(require_value(t, "color", base), base + ".color"));
         }
         if (T == "CHECKERBOARD" || T == "CHECKER") {
             double scale = parse_floatlike(require_value(t, "scale", base), base + ".scale");
             const auto &arr = parse_array(require_value(t, "textures", base), base + ".textures");
             if (arr.size() != 2) throw Error(base + ".textures must be an array of length 2.");
-            Color c0 = parse_color(arr[0], base + ".textures.0");
-            Color c1 = parse_color(arr[1], base + ".textures.1");
+            if (extended && (arr[0].type == Value::STRING || arr[1].type == Value::STRING)) {
+                // names of textures listed earlier in the file (the reference takes two colours)
+                TexturePtr sub[2];
+                for (int k = 0; k < 2; ++k) {
+                    const std::string key = base + ".textures." + std::to_string(k);
+                    auto named = arr[k].type == Value::STRING ? textures.find(arr[k].s) : textures.end();
+                    sub[k] = named != textures.end() ? named->second : std::make_shared<SolidColor>(color(arr[k], key));
+                }
+                return std::make_shared<Checkerboard>(scale, sub[0], sub[1]);
+            }
+            Color c0 = color(arr[0], base + ".textures.0");
+            Color c1 = color(arr[1], base + ".textures.1");
             return Checkerboard::solid(scale, c0, c1);
         }
         if (T == "IMAGE") {
             const Value &pv = require_value(t, "path", base);
             if (pv.type != Value::STRING) throw Error(base + ".path must be a valid filepath.");
-            return ImageTexture::load(pv.s); // throws "Failed to find file ..." like config.rs:347-356
+            const bool relative = !pv.s.empty() && pv.s[0] != '/';
+            // throws "Failed to find file ..." like config.rs:347-356
+            return ImageTexture::load(extended && relative && !base_dir.empty() ? base_dir + "/" + pv.s : pv.s);
+        }
+        if (extended && (T == "NOISE" || T == "PERLIN")) {
+            double scale = parse_floatlike(require_value(t, "scale", base), base + ".scale");
+            const auto &rv = parse_array(require_value(t, "ranvec", base), base + ".ranvec");
+            const auto &pm = parse_array(require_value(t, "perm", base), base + ".perm");
+            if (rv.size() != 256 || pm.size() != 3) throw Error(base + ": ranvec must hold 256 vectors and perm 3 permutations.");
+            std::vector<double> vec(768);
+            std::vector<int32_t> perm(768);
+            for (int i = 0; i < 256; ++i) {
+                Vec3 v = parse_vec3(rv[i], base + ".ranvec." + std::to_string(i), "vector");
+                vec[3 * i] = v.x, vec[3 * i + 1] = v.y, vec[3 * i + 2] = v.z;
+            }
+            for (int a = 0; a < 3; ++a) {
+                const auto &row = parse_array(pm[a], base + ".perm." + std::to_string(a));
+                if (row.size() != 256) throw Error(base + ".perm rows must hold 256 entries.");
+                for (int i = 0; i < 256; ++i) {
+                    if (row[i].type != Value::INTEGER || row[i].i < 0 || row[i].i > 255)
+                        throw Error(base + ".perm entries must be integers 0..255.");
+                    perm[a * 256 + i] = int32_t(row[i].i);
+                }
+            }
+            return std::make_shared<NoiseTexture>(scale, vec.data(), perm.data());
         }
         throw Error(base + ".type must be a valid texture type. (valid: \"color\" | \"checkerboard\" | \"image\")");
     }
@@ -452,21 +525,26 @@ struct Loader {
         std::string base = "config.materials." + name;
         if (!ty) throw Error(base + ".type must be a string.");
         std::string T = upper(*ty);
-        if (T == "LAMBERTIAN") return std::make_shared<Lambertian>(texture_by_name(require_value(t, "texture", base), base + ".texture"));
+        if (T == "LAMBERTIAN")
+            return std::make_shared<Lambertian>(extended ? texture_or_color(t, base)
+                                                         : texture_by_name(require_value(t, "texture", base), base + ".texture"));
         if (T == "METAL" || T == "METALLIC" || T == "FUZZY") {
-            Color albedo = parse_color(require_value(t, "albedo", base), base + ".albedo");
+            Color albedo = color(require_value(t, "albedo", base), base + ".albedo");
             double fuzz = parse_floatlike(require_value(t, "fuzz", base), base + ".fuzz");
             if (fuzz > 1.0) fuzz /= 100.0; // config.rs:417-419
             return Metal::with_fuzz(albedo, fuzz);
         }
         if (T == "LIGHT" || T == "LIGHTSOURCE" || T == "DIFFUSELIGHT")
-            return std::make_shared<DiffuseLight>(texture_by_name(require_value(t, "texture", base), base + ".texture"));
+            return std::make_shared<DiffuseLight>(extended ? texture_or_color(t, base)
+                                                           : texture_by_name(require_value(t, "texture", base), base + ".texture"));
         if (T == "DIELECTRIC")
             return std::make_shared<Dielectric>(parse_floatlike(require_value(t, "refractive_index", base), base + ".refractive_index"));
-        if (T == "ISOTROPIC") return std::make_shared<Isotropic>(texture_by_name(require_value(t, "texture", base), base + ".texture"));
-        if (T == "SOLIDCOLOR") return Lambertian::solid(parse_color(require_value(t, "color", base), base + ".color"));
+        if (T == "ISOTROPIC")
+            return std::make_shared<Isotropic>(extended ? texture_or_color(t, base)
+                                                        : texture_by_name(require_value(t, "texture", base), base + ".texture"));
+        if (T == "SOLIDCOLOR") return Lambertian::solid(color(require_value(t, "color", base), base + ".color"));
         if (T == "COLOREDLIGHT") {
-            Color c = parse_color(require_value(t, "color", base), base + ".color");
+            Color c = color(require_value(t, "color", base), base + ".color");
             auto it = t.find("brightness");
             if (it != t.end()) c.set_brightness(parse_floatlike(it->second, base + ".brightness"));
             return DiffuseLight::solid(c);
@@ -474,11 +552,49 @@ struct Loader {
         throw Error(base + ".type must be a valid material type. (valid: \"metal\" | \"light\" | \"lambertian\" | \"dielectric\")");
     }
 
+    std::map<std::string, HittablePtr> named_objects; // scene files: objects with a `name`
+
     HittablePtr object(size_t index, const Table &t) { // config.rs:498-625
         const std::string *ty = get_type(t);
-        std::string base = "config.objects." + std::to_string(index);
         if (!ty) throw Error("config.materials." + std::to_string(index) + ".type must be a string."); // sic, config.rs:508
-        std::string T = upper(*ty);
+        return object_at("config.objects." + std::to_string(index), t);
+    }
+
+    // an inline object table, or (scene files) the name of an object listed earlier
+    HittablePtr object_value(const Value &v, const std::string &base) {
+        if (v.type == Value::STRING) {
+            auto it = named_objects.find(v.s);
+            if (it == named_objects.end()) throw Error(base + " names an object that has not been listed (" + v.s + ").");
+            return it->second;
+        }
+        if (v.type != Value::TABLE) throw Error(base + " must be a table or the name of an object.");
+        return object_at(base, *v.tab);
+    }
+
+    HittablePtr object_at(const std::string &base, const Table &t) {
+        const std::string *ty = get_type(t);
+        if (!ty) throw Error(base + ".type must be a string.");
+        HittablePtr o = bare_object(base, upper(*ty), t);
+        if (!extended) return o;
+        auto it = t.find("rotate_y"); // instance transforms, in the order of main.rs:45-48
+        if (it != t.end()) // degrees, converted as f64::to_radians does (main.rs:45)
+            o = std::make_shared<RotateY>(o, parse_floatlike(it->second, base + ".rotate_y") * (3.14159265358979323846 / 180.0));
+        it = t.find("translate");
+        if (it != t.end()) o = std::make_shared<Translate>(o, parse_vec3(it->second, base + ".translate", "vector"));
+        it = t.find("light");
+        if (it != t.end()) {
+            if (it->second.type != Value::BOOLEAN) throw Error(base + ".light must be true or false.");
+            if (it->second.b) lights.push_back(o);
+        }
+        it = t.find("name");
+        if (it != t.end()) {
+            if (it->second.type != Value::STRING) throw Error(base + ".name must be a string.");
+            named_objects[it->second.s] = o;
+        }
+        return o;
+    }
+
+    HittablePtr bare_object(const std::string &base, const std::string &T, const Table &t) {
         auto two_vectors = [&](Vec3 out[2]) {
             const auto &vecs = parse_array(require_value(t, "vectors", base), base + ".vectors");
             if (vecs.size() != 2) throw Error(base + ".vectors must be an array of length 2.");
@@ -489,21 +605,24 @@ struct Loader {
             Point3 c = parse_vec3(require_value(t, "center", base), base + ".center", "point");
             double r = parse_floatlike(require_value(t, "radius", base), base + ".radius");
             MaterialPtr m = material_by_name(require_value(t, "material", base), base + ".material");
-            return Sphere::stationary(c, r, m);
+            auto cv = t.find("center_vec"); // scene files: centre(time) = center + time * center_vec (hittable.rs:130-148)
+            if (extended && cv != t.end())
+                return numbered(std::make_shared<Sphere>(c, parse_vec3(cv->second, base + ".center_vec", "vector"), r, m));
+            return numbered(Sphere::stationary(c, r, m));
         }
         if (T == "PARALLELOGRAM") {
             Point3 c = parse_vec3(require_value(t, "corner", base), base + ".corner", "point");
             MaterialPtr m = material_by_name(require_value(t, "material", base), base + ".material");
             Vec3 v[2];
             two_vectors(v);
-            return std::make_shared<Parallelogram>(c, v[0], v[1], m);
+            return numbered(std::make_shared<Parallelogram>(c, v[0], v[1], m));
         }
         if (T == "DISC") {
             Point3 c = parse_vec3(require_value(t, "center", base), base + ".center", "point");
             MaterialPtr m = material_by_name(require_value(t, "material", base), base + ".material");
             Vec3 v[2];
             two_vectors(v);
-            return DiscFromCenter(c, v[0], v[1], m);
+            return numbered(DiscFromCenter(c, v[0], v[1], m));
         }
         if (T == "TRIANGLE") {
             const auto &pts = parse_array(require_value(t, "points", base), base + ".points");
@@ -511,8 +630,42 @@ struct Loader {
             MaterialPtr m = material_by_name(require_value(t, "material", base), base + ".material");
             Point3 p[3];
             for (int i = 0; i < 3; ++i) p[i] = parse_vec3(pts[i], base + ".points." + std::to_string(i), "point");
-            return TriangleFromPoints(p[0], p[1], p[2], m);
+            return numbered(TriangleFromPoints(p[0], p[1], p[2], m));
         }
+        if (extended && T == "BOX") { // box3 (hittable.rs:398-455)
+            Point3 a = parse_vec3(require_value(t, "min", base), base + ".min", "point");
+            Point3 b = parse_vec3(require_value(t, "max", base), base + ".max", "point");
+            MaterialPtr m = material_by_name(require_value(t, "material", base), base + ".material");
+            auto box = box3(a, b, m);
+            for (auto &side : box->objects) numbered(side);
+            return box;
+        }
+        if (extended && (T == "CONSTANTMEDIUM" || T == "MEDIUM")) { // hittable.rs:820-845
+            HittablePtr boundary = object_value(require_value(t, "boundary", base), base + ".boundary");
+            double density = parse_floatlike(require_value(t, "density", base), base + ".density");
+            return numbered(std::make_shared<ConstantMedium>(boundary, density, texture_or_color(t, base)));
+        }
+        if (extended && T == "GROUP") {
+            const auto &kids = parse_array(require_value(t, "children", base), base + ".children");
+            std::vector<HittablePtr> objs;
+            for (size_t i = 0; i < kids.size(); ++i) objs.push_back(object_value(kids[i], base + ".children." + std::to_string(i)));
+            bool bvh = false;
+            auto it = t.find("bvh");
+            if (it != t.end()) {
+                if (it->second.type != Value::BOOLEAN) throw Error(base + ".bvh must be true or false.");
+                bvh = it->second.b;
+            }
+            if (bvh) {
+                if (objs.empty()) throw Error(base + ": a BVH needs at least one child.");
+                return std::make_shared<BVHNode>(std::move(objs)); // BVHNode::new (boundingbox.rs:179-206)
+            }
+            auto list = std::make_shared<HittableVec>();
+            for (auto &o : objs) list->add(o);
+            return list;
+        }
+        if (extended)
+            throw Error(base + ".type must be a valid object type. (valid: \"sphere\" | \"parallelogram\" | \"triangle\" | "
+                               "\"disc\" | \"box\" | \"constantmedium\" | \"group\")");
         throw Error(base + ".type must be a valid object type. (valid: \"sphere\" | \"parallelogram\" | \"triangle\" | \"disc\")");
     }
 };
@@ -550,6 +703,107 @@ ConfigModel ConfigModel::from_str(const std::string &text) { // config.rs:628-70
     }
     cfg.materials = L.materials;
     return cfg;
+}
+
+SceneFile load_scene_file(const std::string &text, const std::string &base_dir, int &next_prim_id) {
+    Parser parser(text);
+    Table root = parser.parse();
+    Loader L;
+    L.extended = true;
+    L.base_dir = base_dir;
+    L.next_prim_id = &next_prim_id;
+    auto table_of = [&](const char *k) -> const Table * { // textures / materials may be left out
+        auto it = root.find(k);
+        if (it == root.end()) return nullptr;
+        if (it->second.type != Value::TABLE) throw Error(std::string("config.") + k + " must be a table.");
+        return it->second.tab.get();
+    };
+    // checkerboards may name other textures, so textures are built in file order where the parser
+    // kept it; the map is in key order (BTreeMap), so a named sub-texture must sort before its user
+    if (const Table *tt = table_of("textures"))
+        for (const auto &kv : *tt) {
+            if (kv.second.type != Value::TABLE) throw Error("config.textures." + kv.first + " must be a table.");
+            L.textures[kv.first] = L.texture(kv.first, *kv.second.tab);
+        }
+    if (const Table *mt = table_of("materials"))
+        for (const auto &kv : *mt) {
+            if (kv.second.type != Value::TABLE) throw Error("config.materials." + kv.first + " must be a table.");
+            L.materials[kv.first] = L.material(kv.first, *kv.second.tab);
+        }
+    auto oit = root.find("objects");
+    if (oit == root.end() || oit->second.type != Value::ARRAY) throw Error("config.objects must be a list of tables.");
+    SceneFile out;
+    auto world = std::make_shared<HittableVec>();
+    size_t i = 0;
+    for (const auto &ov : oit->second.arr) {
+        if (ov.type != Value::TABLE) throw Error("config.objects." + std::to_string(i) + " must be a table.");
+        world->add(L.object_at("config.objects." + std::to_string(i), *ov.tab));
+        ++i;
+    }
+    out.world = world;
+    out.materials = L.materials;
+    // `lights`: one object as it is, several as a HittableVec (which draws the pick, pdf.rs);
+    // light_list = true forces the list form for a single light
+    bool force_list = false;
+    auto ll = root.find("light_list");
+    if (ll != root.end()) {
+        if (ll->second.type != Value::BOOLEAN) throw Error("config.light_list must be true or false.");
+        force_list = ll->second.b;
+    }
+    if (L.lights.size() == 1 && !force_list) {
+        out.lights = L.lights[0];
+    } else if (!L.lights.empty()) {
+        auto lv = std::make_shared<HittableVec>();
+        for (auto &l : L.lights) lv->add(l);
+        out.lights = lv;
+    }
+    rth_camera_defaults(&out.camera);
+    if (const Table *ct = table_of("camera")) { // CameraBuilder setters (camera.rs:57-171)
+        out.has_camera = true;
+        rth_camera_builder &c = out.camera;
+        const std::string base = "config.camera";
+        auto num = [&](const char *k, double &dst) {
+            auto it = ct->find(k);
+            if (it != ct->end()) dst = parse_floatlike(it->second, base + "." + k);
+        };
+        auto uint = [&](const char *k, uint32_t &dst) {
+            auto it = ct->find(k);
+            if (it == ct->end()) return;
+            if (it->second.type != Value::INTEGER || it->second.i < 0 || it->second.i > 0xFFFFFFFFll)
+                throw Error(base + "." + k + " must be a non-negative integer.");
+            dst = uint32_t(it->second.i);
+        };
+        auto vec = [&](const char *k, double dst[3], const char *what) {
+            auto it = ct->find(k);
+            if (it == ct->end()) return;
+            Vec3 v = parse_vec3(it->second, base + "." + k, what);
+            dst[0] = v.x, dst[1] = v.y, dst[2] = v.z;
+        };
+        uint("image_width", c.image_width);
+        uint("image_height", c.image_height);
+        auto ar = ct->find("aspect_ratio");
+        if (ar != ct->end()) // with_aspect_ratio (camera.rs:78-92): height = round(width / ratio)
+            rth_camera_with_aspect_ratio(&c, c.image_width, parse_floatlike(ar->second, base + ".aspect_ratio"));
+        uint("samples_per_px", c.samples_per_px);
+        uint("max_depth", c.max_depth);
+        num("vfov", c.vfov_deg);
+        vec("camera_center", c.center, "point");
+        vec("camera_target", c.target, "point");
+        vec("vup", c.vup, "vector");
+        num("defocus_angle", c.defocus_angle_deg);
+        num("focal_length", c.focal_length);
+        auto bg = ct->find("background");
+        if (bg != ct->end()) {
+            if (bg->second.type == Value::STRING && upper(bg->second.s) == "SKY") {
+                c.background_sky = 1;
+            } else {
+                Color col = parse_color_ext(bg->second, base + ".background");
+                c.background_sky = 0;
+                c.background[0] = col.r, c.background[1] = col.g, c.background[2] = col.b;
+            }
+        }
+    }
+    return out;
 }
 
 std::shared_ptr<HittableVec> ConfigModel::as_world() const { // config.rs:691-697

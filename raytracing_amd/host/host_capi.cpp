@@ -248,6 +248,17 @@ int rth_load_toml(rth_scene *s, const char *text) {
         return push_obj(s, world);
     });
 }
+int rth_load_scene_toml(rth_scene *s, const char *text, const char *base_dir, rth_camera_builder *camera, int *has_camera) {
+    return guarded(s, [&] {
+        SceneFile f = load_scene_file(text ? text : "", base_dir ? base_dir : "", s->nprims);
+        for (auto &kv : f.materials) s->named_materials[kv.first] = push_mat(s, kv.second);
+        s->world = f.world;
+        s->lights = f.lights;
+        if (camera) *camera = f.camera;
+        if (has_camera) *has_camera = f.has_camera ? 1 : 0;
+        return push_obj(s, f.world);
+    });
+}
 int rth_material_by_name(rth_scene *s, const char *name) {
     auto it = s->named_materials.find(name ? name : "");
     if (it == s->named_materials.end()) return fail(s, std::string("no material named ") + (name ? name : ""));

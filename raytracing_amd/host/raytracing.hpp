@@ -330,6 +330,17 @@ class ConfigModel {
     std::vector<HittablePtr> objects;
 };
 
+// A scene file: ConfigModel's format plus what a whole render needs (see config.cpp).
+struct SceneFile {
+    std::shared_ptr<HittableVec> world;
+    HittablePtr lights; // null when no object is marked `light = true`
+    std::map<std::string, MaterialPtr> materials;
+    bool has_camera = false;
+    rth_camera_builder camera; // defaults of camera.rs:183-202 overridden by [camera]
+};
+// Primitives are numbered from next_prim_id in the order the file lists them.
+SceneFile load_scene_file(const std::string &toml_text, const std::string &base_dir, int &next_prim_id);
+
 // ------------------------------------------------------------------ image writers (export.rs)
 void write_png(const std::string &path, uint32_t w, uint32_t h, const float *rgb); // linear, truncating
 void write_ppm(const std::string &path, uint32_t w, uint32_t h, const float *rgb); // gamma 2, truncating

@@ -510,3 +510,36 @@ def test_progressive_render_resumes_from_a_checkpoint(device, tmp_path):
     assert np.array_equal(png, device.film_rgb8(1.0 / cam.effective_spp))
     with pytest.raises(ValueError):
         ra.progressive.render_progressive(device, cam, mode, seed=10, checkpoint_path=ck_path)
+
+
+def test_render_from_a_scene_file_matches_the_oracle_reading_the_same_file(device, tmp_path):
+    """The whole workload as data: product and oracle each read the file with their own
+    loader (rth_load_scene_toml / config_oracle.load_scene) and render the same image."""
+    from oracle import config_oracle
+    from raytracing_amd import scene_toml
+    fn, kw, mode, _, _ = SCENES["c4"]  # media, instances, image + noise textures, motion blur, a BVH
+    rec = scene_toml.TomlRecorder()
+    cam = fn(rec, **kw)
+    rec.save(tmp_path / "c4.toml", cam)
+    host = ra.SceneBuilder()
+    cam_file = scene_toml.load_scene_file(host, tmp_path / "c4.toml")
+    osb = orc.scene()
+    ocam = ra.CameraSettings(**config_oracle.load_scene(osb, (tmp_path / "c4.toml").read_text(), tmp_path))
+    assert cam_file == ocam == cam and host.prim_count() == osb.prim_count()
+    device.upload(host)
+    device.film_resize(cam.image_width, cam.image_height)
+    st = device.render(cam_file.build(), mode=mode, seed=1)
+    gpu = device.film(1.0 / cam.effective_spp)
+    film, _, cnt = orc.render(osb, ocam, mode=mode, seed=1)
+    r = helpers.compare_same_stream(gpu, film / cam.effective_spp)
+    assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.08, r
+    assert st.camera_rays == cnt["camera_rays"]
+    # the committed full-size files load and render too (a few strata of the Cornell box)
+    root = Path(ra.__file__).resolve().parent.parent / "scenes"
+    host3 = ra.SceneBuilder()
+    cam3 = scene_toml.load_scene_file(host3, root / "cornell_book3" / "cornell_book3.toml")
+    cam3 = ra.CameraSettings(**{**cam3.__dict__, "image_width": 96, "image_height": 96})
+    device.upload(host3)
+    device.film_resize(96, 96)
+    st3 = device.render(cam3.build(), mode=ra.RT_MODE_BOOK3, seed=1, stratum_begin=0, stratum_end=4)
+    assert st3.camera_rays == 96 * 96 * 4 and np.isfinite(device.film()).all() and device.film().mean() > 0

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Writes the workloads as scene files under scenes/ (TOML + PNG textures) by running the scene
+functions of raytracing_amd.scenes against a recorder.  The five configurations:
+cornell_main (C1), book1_final (C2), cornell_book3 (C3), book2_final (C4) and stress (C5; the
+committed file holds 3000 primitives, `--stress-prims 1000000` writes the full one)."""
+import argparse
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import raytracing_amd as ra  # noqa: E402
+from raytracing_amd.scene_toml import TomlRecorder  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--out", default=str(ROOT / "scenes"))
+ap.add_argument("--stress-prims", type=int, default=3000)
+ap.add_argument("--earth", default="512x256", help="size of the synthetic earth texture of book2_final")
+args = ap.parse_args()
+out = Path(args.out)
+ew, eh = (int(x) for x in args.earth.split("x"))
+jobs = {
+    "cornell_main": (ra.scenes.cornell_main, {}),
+    "book1_final": (ra.scenes.book1_final, {}),
+    "cornell_book3": (ra.scenes.cornell_book3, {}),
+    "book2_final": (ra.scenes.book2_final, dict(earth=ra.scenes.synthetic_earth(ew, eh))),
+    "stress": (ra.scenes.stress, dict(n_prims=args.stress_prims, extent=100.0 if args.stress_prims >= 100000 else 6.0)),
+}
+for name, (fn, kw) in jobs.items():
+    rec = TomlRecorder()
+    cam = fn(rec, **kw)
+    d = out / name
+    d.mkdir(parents=True, exist_ok=True)
+    rec.save(d / f"{name}.toml", cam)
+    print(name, (d / f"{name}.toml").stat().st_size, "bytes")
