@@ -218,6 +218,10 @@ typedef struct {
     double cost;            /* wide only: expected box tests of a random ray through the root box */
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
+/* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it
+ * against the descriptor -- same leaves, boxes that contain their content, forward indices.
+ * stack_entries reports the exact stack need.  Returns 0, or < 0 with the reason in err. */
+int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_info *out, char *err, uint32_t err_len);
 
 /* The pixel x stratum loop of camera.rs:386-401 for strata [begin,end): every sample's
  * radiance is ADDED into the film (planar fp32 sums in HBM).  Asynchronous on the stream

@@ -111,6 +111,7 @@ SIGNATURES = {
     "rt_film_device_ptr": (C.c_int, [_vp, P(_vp), P(u64)]),
     "rt_set_accel": (C.c_int, [_vp, u32, u32]),
     "rt_get_accel_info": (C.c_int, [_vp, P(RtAccelInfo)]),
+    "rt_accel_selftest": (C.c_int, [P(RtSceneDesc), u32, P(RtAccelInfo), C.c_char_p, u32]),
     "rt_film_download": (C.c_int, [_vp, P(f32), f32]),
     "rt_film_upload": (C.c_int, [_vp, P(f32), u32, u32]),
     "rt_film_quantize": (C.c_int, [_vp, P(C.c_uint8), f64, u32]),

@@ -398,5 +398,57 @@ inline std::string build_wide_bvh(const rt_scene_desc *s, uint32_t builder, std:
     return "";
 }
 
+// Structural check of a built tree against its scene: every primitive the descriptor's world
+// reaches is a leaf exactly as often as the descriptor reaches it, every child box contains what
+// is below it, indices point forward.  Returns "" or what is wrong.
+inline std::string verify_wide_bvh(const rt_scene_desc *s, const std::vector<Node4> &nodes) {
+    if (nodes.empty()) return "no nodes";
+    // leaves the descriptor reaches (with multiplicity)
+    std::vector<uint32_t> want;
+    {
+        std::vector<uint32_t> todo{s->root};
+        while (!todo.empty()) {
+            uint32_t r = todo.back();
+            todo.pop_back();
+            if ((r >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
+                want.push_back(r);
+                continue;
+            }
+            const rt_node &n = s->nodes[r & RT_REF_INDEX_MASK];
+            if (n.right == RT_NODE_LEAF)
+                for (uint32_t k = 0; k < n.count; ++k) todo.push_back(s->refs[n.left + k]);
+            else
+                todo.push_back(n.left), todo.push_back(n.right);
+        }
+    }
+    Builder b(s);
+    std::vector<uint32_t> got;
+    std::vector<Box> below(nodes.size());
+    for (size_t i = nodes.size(); i-- > 0;) {
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = nodes[i].child[k];
+            if (c == RT_REF_NONE) continue;
+            Box stored;
+            for (int a = 0; a < 3; ++a) stored.lo[a] = nodes[i].lo[a][k], stored.hi[a] = nodes[i].hi[a][k];
+            Box content;
+            if ((c >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) {
+                const uint32_t j = c & RT_REF_INDEX_MASK;
+                if (j <= i || j >= nodes.size()) return "child index does not point forward";
+                content = below[j];
+            } else {
+                content = b.prim_box(c);
+                got.push_back(c);
+            }
+            for (int a = 0; a < 3; ++a)
+                if (!(stored.lo[a] <= content.lo[a] && stored.hi[a] >= content.hi[a])) return "child box does not contain its content";
+            below[i].add(stored);
+        }
+    }
+    std::sort(want.begin(), want.end());
+    std::sort(got.begin(), got.end());
+    if (want != got) return "leaves differ from the primitives the descriptor reaches";
+    return "";
+}
+
 } // namespace accel
 } // namespace rt

@@ -584,6 +584,27 @@ int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width) {
     return 0;
 }
 
+int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_info *out, char *err, uint32_t err_len) {
+    auto say = [&](const std::string &m) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", m.c_str());
+        return -1;
+    };
+    if (!scene || builder > RT_BUILD_AUTO) return say("rt_accel_selftest: bad argument");
+    rt_handle tmp; // validate_scene only records its message in the handle
+    if (validate_scene(&tmp, scene)) return say(tmp.err);
+    std::vector<Node4> nodes;
+    uint32_t root = 0;
+    accel::Stats st;
+    std::string e = accel::build_wide_bvh(scene, builder, nodes, root, st);
+    if (e.empty()) e = accel::verify_wide_bvh(scene, nodes);
+    if (!e.empty()) return say("rt_accel_selftest: " + e);
+    if (out) {
+        out->kind = uint32_t(ACCEL_BVH4);
+        out->nodes = st.nodes, out->depth = st.depth, out->stack_entries = st.stack_need, out->cost = st.cost;
+    }
+    return 0;
+}
+
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     if (!h || !out) return -1;
     if (!h->have_scene) return fail(h, "rt_get_accel_info: no scene uploaded");
