@@ -38,6 +38,8 @@ struct rt_handle {
     int accel = ACCEL_BVH2;                 // structure the kernels search for this scene
     uint32_t build = RT_BUILD_AUTO, width = 4; // rt_set_accel: applies to the next upload
     uint32_t stack4 = 0;                    // LDS stack entries per lane of the wide traversal
+    uint32_t lds_nodes4 = 0;                // wide nodes staged in LDS behind the stack
+    size_t dyn_lds4() const { return size_t(stack4) * BLOCK * sizeof(uint32_t) + size_t(lds_nodes4) * sizeof(Node4); }
     accel::Stats accel_stats{};
     uint32_t has_media = 0, n_prims = 0;
     bool has_specular = false;
@@ -310,7 +312,7 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
                  unsigned long long total) {
     auto kernel = k_paths<MODE, ACCEL>;
     int per_cu = 0, n_cu = 0;
-    const size_t dyn_lds = ACCEL == ACCEL_BVH4 ? size_t(h->stack4) * BLOCK * sizeof(uint32_t) : 0;
+    const size_t dyn_lds = ACCEL == ACCEL_BVH4 ? h->dyn_lds4() : 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
@@ -506,7 +508,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     }
     // structure the kernels will search
     std::vector<Node4> nodes4;
-    h->stack4 = 0;
+    h->stack4 = h->lds_nodes4 = 0;
     h->accel_stats = accel::Stats();
     if (h->flat) {
         h->accel = ACCEL_FLAT;
@@ -519,6 +521,10 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
         if (h->accel_stats.stack_need <= 64 && nodes4.size() < (1u << 25)) { // byte offsets of nodes stay 32-bit
             h->accel = ACCEL_BVH4;
             h->stack4 = std::max(8u, (h->accel_stats.stack_need + 3u) & ~3u);
+            // what is left of a quarter of the CU's 160 KB (four resident blocks) holds the top of the tree
+            // (measured: 52 or 64 KB per block stage more nodes but lose a resident block: slower)
+            const size_t budget = 40 * 1024, stack_bytes = size_t(h->stack4) * BLOCK * sizeof(uint32_t);
+            h->lds_nodes4 = stack_bytes < budget ? uint32_t(std::min<size_t>(nodes4.size(), (budget - stack_bytes) / sizeof(Node4))) : 0u;
         } else {
             nodes4.clear(); // too deep for the LDS stack of the wide traversal: binary nodes as given
             h->accel = ACCEL_BVH2;
@@ -530,6 +536,8 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
         return fail(h, "rt_upload_scene: scene needs a deeper traversal stack than the kernels provide (" +
                            std::to_string(s->max_stack) + " > " + std::to_string(STACK_DEPTH) + ")");
     d.n_nodes4 = uint32_t(nodes4.size());
+    d.stack4 = h->stack4;
+    d.lds_nodes4 = h->lds_nodes4;
     d.n_flat_quads = uint32_t(flat_quads.size() / 16);
     // the scan requests records in pairs, one pair ahead: pad with records that cannot hit
     flat_quads.resize((size_t(d.n_flat_quads) + 3) / 2 * 2 * 16, 0.0f);
@@ -769,7 +777,7 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     const bool timing = (p->flags & RT_FLAG_TIME_KERNELS) != 0;
     const uint32_t time_every = p->time_every ? p->time_every : 1u;
     Timer tm{h, false};
-    const size_t dyn_lds = size_t(h->stack4) * BLOCK * sizeof(uint32_t); // wide traversal stack
+    const size_t dyn_lds = h->dyn_lds4(); // wide traversal: stack + staged nodes
     uint64_t iter_no = p->seed; // rotate which iterations are timed from render to render
 
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
@@ -870,7 +878,7 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (e == hipSuccess && time) e = hipMemcpyAsync(d_time, time, size_t(n) * sizeof(float), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
-        const size_t dyn_lds = size_t(h->stack4) * BLOCK * sizeof(uint32_t);
+        const size_t dyn_lds = h->dyn_lds4();
         if (h->accel == ACCEL_FLAT)
             k_intersect_batch<ACCEL_FLAT><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
                                                                          d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));

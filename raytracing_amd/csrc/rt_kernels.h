@@ -52,6 +52,8 @@ struct DScene {
     // 4-wide BVH derived at upload (rt_accel.h): 8 float4 per node, root = node 0
     const float4 *nodes4;
     uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_other, n_nodes4;
+    // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
+    uint32_t stack4, lds_nodes4;
 };
 
 // which structure a kernel instance searches
@@ -381,8 +383,22 @@ __device__ __forceinline__ void traverse(SceneRef sc, V3 o, V3 d, float time, fl
 // lanes of the wave have left it, so a wave does not execute node code and primitive code for
 // one lane each per iteration.  Children are visited nearest first; the others go on the stack
 // farthest first.  Visiting order cannot change the closest hit.
+// The top of the tree (nodes are numbered breadth first) is staged in LDS by stage_nodes4: every
+// ray starts there, and a per-lane 16-byte read costs the LDS a fraction of what 64 scattered
+// cache lines cost the vector memory path.  A lane reads a node through a generic pointer that
+// points into LDS or into global memory, so both cases are one instruction stream.
+__device__ __forceinline__ void stage_nodes4(SceneRef sc, uint32_t *s_dyn) {
+    const uint32_t n = sc.lds_nodes4 * 8u;
+    float4 *dst = reinterpret_cast<float4 *>(s_dyn + size_t(sc.stack4) * BLOCK);
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) dst[i] = sc.nodes4[i];
+    __syncthreads();
+}
+// STAGED = false reads every node from global memory with plain global loads (generic loads
+// cost ~13 % on a scene too deep to leave LDS for nodes).
+template <bool STAGED>
 __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
-                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *stack, Best &best) {
+                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *s_dyn, Best &best) {
+    uint32_t *stack = s_dyn + threadIdx.x;
     best.t = thi;
     best.ref = best.mat = RT_REF_NONE;
     best.u = best.v = 0.f;
@@ -394,16 +410,19 @@ __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, f
     // per-axis min/max is needed.  Sign bit, not `< 0`: -0 has reciprocal -inf.
     const uint32_t nx = (fbits(d.x) >> 31) * 48u, ny = 16u + (fbits(d.y) >> 31) * 48u, nz = 32u + (fbits(d.z) >> 31) * 48u;
     const uint32_t fx = 48u - nx, fy = 80u - ny, fz = 112u - nz; // the other plane of each axis
-    const char *nodes = reinterpret_cast<const char *>(sc.nodes4);
-    auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(nodes + byte_off); };
+    const char *g_nodes = reinterpret_cast<const char *>(sc.nodes4);
+    const char *l_nodes = reinterpret_cast<const char *>(s_dyn + size_t(sc.stack4) * BLOCK);
+    const uint32_t lds_bytes = sc.lds_nodes4 * 128u;
     uint32_t sp = 0;
     uint32_t cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
     for (;;) {
         while ((cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) {
             const uint32_t nb = (cur & RT_REF_INDEX_MASK) * 128u; // the wide array stays below 4 GiB (checked at upload)
-            const float4 ax = ld(nb + nx), ay = ld(nb + ny), az = ld(nb + nz);
-            const float4 bx = ld(nb + fx), by = ld(nb + fy), bz = ld(nb + fz);
-            const float4 cf = ld(nb + 96u);
+            const char *node = (STAGED && nb < lds_bytes ? l_nodes : g_nodes) + nb;
+            auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(node + byte_off); };
+            const float4 ax = ld(nx), ay = ld(ny), az = ld(nz);
+            const float4 bx = ld(fx), by = ld(fy), bz = ld(fz);
+            const float4 cf = ld(96u);
             uint32_t ref[4] = {fbits(cf.x), fbits(cf.y), fbits(cf.z), fbits(cf.w)};
             // BoundingBox3::hit (boundingbox.rs:96-113) for four boxes; see hit_box for the slack.
             // 0 * inf = NaN where the origin lies on a plane the ray is parallel to: max3/min3
@@ -537,7 +556,10 @@ __device__ __forceinline__ void closest_hit(SceneRef sc, V3 o, V3 d, float time,
     else if (ACCEL == ACCEL_BVH2)
         traverse<USE_LDS_NODES>(sc, o, d, time, tlo, thi, origin_ref, rc, s_stack + threadIdx.x, s_nodes, best);
     else
-        traverse4(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn + threadIdx.x, best);
+        if (sc.lds_nodes4) // uniform
+            traverse4<true>(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn, best);
+        else
+            traverse4<false>(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn, best);
 }
 
 // LDS the three structures need, declared once per kernel
@@ -793,6 +815,7 @@ template <int ACCEL>
 __global__ void __launch_bounds__(BLOCK) k_extend(Queue q, const DScene *scp, uint32_t k0, uint32_t k1, uint32_t has_media) {
     SceneRef sc = *as_uniform(scp);
     RT_ACCEL_LDS(ACCEL)
+    if (ACCEL == ACCEL_BVH4) stage_nodes4(sc, s_dyn);
     if (ACCEL == ACCEL_BVH2) { // stage the top of the BVH
         const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
         const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
@@ -1067,6 +1090,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     SceneRef sc = *as_uniform(scp);
     CamRef cam = *as_uniform(camp);
     RT_ACCEL_LDS(ACCEL)
+    if (ACCEL == ACCEL_BVH4) stage_nodes4(sc, s_dyn);
     if (ACCEL == ACCEL_BVH2) {
         const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
         const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
@@ -1168,6 +1192,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(const DScene *scp, ui
                                                             int *prim, float *t, float *u, float *v) {
     SceneRef sc = *as_uniform(scp);
     RT_ACCEL_LDS(ACCEL)
+    if (ACCEL == ACCEL_BVH4) stage_nodes4(sc, s_dyn);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     V3 o = {o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d = {d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};
