@@ -543,3 +543,33 @@ def test_render_from_a_scene_file_matches_the_oracle_reading_the_same_file(devic
     device.film_resize(96, 96)
     st3 = device.render(cam3.build(), mode=ra.RT_MODE_BOOK3, seed=1, stratum_begin=0, stratum_end=4)
     assert st3.camera_rays == 96 * 96 * 4 and np.isfinite(device.film()).all() and device.film().mean() > 0
+
+
+@pytest.mark.parametrize("wavefront", [False, True], ids=["persistent", "wavefront"])
+def test_edge_sizes(device, wavefront):
+    """Empty, tiny and ragged inputs: an empty ray batch, the smallest image CameraBuilder
+    accepts (2x2, camera.rs:105-116), sizes that are not a multiple of the 64-lane wave or of the
+    4-pixel packing of the output stage, one sample per pixel, an empty stratum range, fewer
+    samples than one wave."""
+    host, osb, cam, mode, _ = scene("c3", device)
+    empty = device.intersect_batch(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert all(len(a) == 0 for a in empty)
+    for w, h, spp in ((2, 2, 1), (2, 2, 16), (7, 3, 4), (65, 2, 1), (33, 31, 9)):
+        c = ra.CameraSettings(**{**cam.__dict__, "image_width": w, "image_height": h, "samples_per_px": spp})
+        oc = ra.CameraSettings(**{**cam.__dict__, "image_width": w, "image_height": h, "samples_per_px": spp})
+        device.film_resize(w, h)
+        st = device.render(c.build(), mode=mode, seed=3, wavefront=wavefront)
+        film, _, cnt = orc.render(osb, oc, mode=mode, seed=3)
+        assert st.camera_rays == w * h * c.effective_spp == cnt["camera_rays"]
+        gpu = device.film(1.0 / c.effective_spp)
+        assert gpu.shape == (h, w, 3) and np.isfinite(gpu).all()
+        r = helpers.compare_same_stream(gpu, film / c.effective_spp)
+        assert r["frac_5e2"] <= 0.1 + 2.0 / (w * h), (w, h, spp, r)  # a forked path is a whole pixel of a tiny image
+        assert device.film_rgb8(1.0 / c.effective_spp).shape == (h, w, 3)
+    # an empty stratum range renders nothing and leaves the film alone
+    device.film_resize(8, 8)
+    c = ra.CameraSettings(**{**cam.__dict__, "image_width": 8, "image_height": 8, "samples_per_px": 16})
+    st = device.render(c.build(), mode=mode, seed=3, stratum_begin=5, stratum_end=5, wavefront=wavefront)
+    assert st.camera_rays == 0 and st.segments == 0 and not device.film().any()
+    with pytest.raises(ra.RtError, match="greater than 1"):
+        ra.CameraSettings(**{**cam.__dict__, "image_width": 1, "image_height": 1}).build()
