@@ -227,6 +227,7 @@ int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCa
     d.npix = d.W * d.H;
     d.sqrt_spp = c->sqrt_spp;
     d.inv_sqrt = float(1.0 / double(c->sqrt_spp));
+    d.inv_w = float(1.0 / double(c->image_width));
     d.stratum_begin = sb;
     d.max_depth = c->max_depth;
     d.defocus = !(c->defocus_angle <= 0.0); // camera.rs:422
@@ -538,13 +539,39 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.n_nodes4 = uint32_t(nodes4.size());
     d.stack4 = h->stack4;
     d.lds_nodes4 = h->lds_nodes4;
+    // parallelograms only: the same records two per 32 floats, fields interleaved
+    std::vector<float> flat_pairs;
+    {
+        const size_t nq = flat_quads.size() / 16;
+        bool all_par = nq > 0;
+        for (size_t i = 0; i < nq; ++i) {
+            uint32_t shape;
+            std::memcpy(&shape, &flat_quads[16 * i + 11], 4);
+            all_par = all_par && shape == RT_SHAPE_PARALLELOGRAM;
+        }
+        if (all_par) {
+            flat_pairs.assign((nq + 1) / 2 * 32, 0.0f); // an odd count leaves a zero normal: never hit
+            for (size_t i = 0; i < nq; ++i) {
+                const float *q = &flat_quads[16 * i];
+                float *pr = &flat_pairs[(i / 2) * 32];
+                const size_t j = i & 1;
+                const int src[12] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14}; // q, n, avec, bvec
+                for (int f = 0; f < 12; ++f) pr[2 * f + j] = q[src[f]];
+                pr[24 + j] = q[3]; // ref bits
+                pr[26 + j] = q[7]; // material bits
+            }
+            const uint32_t none = RT_REF_NONE;
+            if (nq & 1) std::memcpy(&flat_pairs[(nq / 2) * 32 + 25], &none, 4);
+        }
+    }
+    d.n_flat_pairs = uint32_t(flat_pairs.size() / 32);
     d.n_flat_quads = uint32_t(flat_quads.size() / 16);
     // the scan requests records in pairs, one pair ahead: pad with records that cannot hit
     flat_quads.resize((size_t(d.n_flat_quads) + 3) / 2 * 2 * 16, 0.0f);
     d.n_flat_other = uint32_t(flat_other.size());
     if (upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, s->spheres, s->n_spheres, &ds) ||
-        upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, nodes4.data(), nodes4.size(), &dn4) ||
+        upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || upload(h, nodes4.data(), nodes4.size(), &dn4) ||
         upload(h, flat_other.data(), flat_other.size(), &d.flat_other) ||
         upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
         upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) ||

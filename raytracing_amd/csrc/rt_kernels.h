@@ -48,10 +48,11 @@ struct DScene {
     // a world that is one list of primitives: its quads packed in list order, 16 floats each
     // (q.xyz ref | n.xyz mat | avec.xyz shape | bvec.xyz -), and the refs of everything else
     const float *flat_quads;
+    const float *flat_pairs; // the same quads two per record when all are parallelograms (see scan_flat)
     const uint32_t *flat_other;
     // 4-wide BVH derived at upload (rt_accel.h): 8 float4 per node, root = node 0
     const float4 *nodes4;
-    uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_other, n_nodes4;
+    uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_pairs, n_flat_other, n_nodes4;
     // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
     uint32_t stack4, lds_nodes4;
 };
@@ -62,7 +63,7 @@ enum : int { ACCEL_FLAT = 0, ACCEL_BVH2 = 1, ACCEL_BVH4 = 2 };
 struct DCamera {
     V3 p00_rel, du, dv, center, disk_u, disk_v, bg;
     uint32_t W, H, npix, sqrt_spp, stratum_begin, max_depth, defocus, sky;
-    float inv_sqrt;
+    float inv_sqrt, inv_w;
 };
 
 // Scene and camera live in device memory and are read through the constant address space:
@@ -532,7 +533,49 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
     // packed array ends with an all-zero record after an odd count (a zero normal never hits)
     // and one more after that, so requests need no bounds and the loop body has no branch.
     // The asm statements keep each request where it is written.
-    if (nq) {
+    if (sc.n_flat_pairs) {
+        // Parallelograms only (the usual case: walls and boxes): two quads per record, their
+        // fields interleaved so that every packed instruction takes its scalar operand straight
+        // from the loaded register pair, and the accept rule folded into two max3 and a compare
+        // -- 49 vector and ~10 scalar instructions per pair (the general loop below: 64 and ~75;
+        // the scalar unit issues as slowly as the vector units, so both count).
+        //   pair record, 32 floats: qx qy qz nx ny nz ax ay az bx by bz (2 each), ref[2], mat[2], pad
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const RT_CONST_AS float *P = as_uniform(sc.flat_pairs);
+        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+        for (uint32_t k = 0; k < sc.n_flat_pairs; ++k, P += 32) {
+            auto f2 = [&](int i) { return v2f{P[2 * i], P[2 * i + 1]}; };
+            // the whole record is requested at once, behind one wait (left alone, the compiler
+            // fetches refs and materials only where a hit needs them, each behind its own wait)
+            const float ref_bits[2] = {P[24], P[25]}, mat_bits[2] = {P[26], P[27]};
+            const v2f first = f2(0), last = f2(11);
+            asm volatile("" ::"s"(ref_bits[0]), "s"(ref_bits[1]), "s"(mat_bits[0]), "s"(mat_bits[1]), "s"(first), "s"(last));
+            const v2f nx = f2(3), ny = f2(4), nz = f2(5);
+            const v2f denom = nx * dx + ny * dy + nz * dz;
+            const v2f qox = f2(0) - ox, qoy = f2(1) - oy, qoz = f2(2) - oz;
+            const v2f num = nx * qox + ny * qoy + nz * qoz;
+            const v2f tt = num * v2f{__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
+            const v2f phx = dx * tt - qox, phy = dy * tt - qoy, phz = dz * tt - qoz;
+            const v2f alpha = phx * f2(6) + phy * f2(7) + phz * f2(8);
+            const v2f beta = phx * f2(9) + phy * f2(10) + phz * f2(11);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { // in list order: the second sees the first's closest
+                const float a = alpha[j], b = beta[j], t = tt[j];
+                const uint32_t r = fbits(ref_bits[j]);
+                // 0 <= a, b <= 1 and tlo <= t <= closest  <=>  the largest violation is <= 0
+                // (differences keep their sign exactly; NaN only arises from denom = 0, rejected below)
+                const float outside = fmaxf(fmaxf(-a, -b), fmaxf(a, b) - 1.0f);
+                const float worst = fmaxf(fmaxf(outside, tlo - t), t - best.t);
+                const bool ok = (worst <= 0.0f) & (fabsf(denom[j]) >= 1e-8f) & (r != origin_ref);
+                best.t = ok ? t : best.t;
+                best.ref = ok ? r : best.ref;
+                best.u = ok ? a : best.u;
+                best.v = ok ? b : best.v;
+                best.mat = ok ? fbits(mat_bits[j]) : best.mat;
+            }
+        }
+    } else if (nq) {
         QuadRec a = load_quad_rec(Q);
         for (uint32_t k = 0; k < nq; k += 2) {
             const QuadRec b = load_quad_rec(Q + 16 * size_t(k + 1));
@@ -701,8 +744,24 @@ __device__ __forceinline__ float lights_pdf(SceneRef sc, V3 p, V3 dir) {
 // rng: the (pixel, stratum) camera stream, begun by the caller
 __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t stratum, Rng &rng, V3 &o,
                                            V3 &d, float &time) {
-    uint32_t i = pixel % cam.W, j = pixel / cam.W;
-    uint32_t si = stratum % cam.sqrt_spp, sj = stratum / cam.sqrt_spp;
+    // row and column by a float reciprocal with one correction step: exact below 2^24, where
+    // the integer division costs ~25 instructions apiece
+    uint32_t i, j, si, sj;
+    if (cam.npix < (1u << 24) && cam.sqrt_spp < 4096u) {
+        j = uint32_t(float(pixel) * cam.inv_w);
+        int32_t r = int32_t(pixel - j * cam.W);
+        j += r >= int32_t(cam.W) ? 1u : 0u;
+        j -= r < 0 ? 1u : 0u;
+        i = pixel - j * cam.W;
+        sj = uint32_t(float(stratum) * cam.inv_sqrt);
+        int32_t rs = int32_t(stratum - sj * cam.sqrt_spp);
+        sj += rs >= int32_t(cam.sqrt_spp) ? 1u : 0u;
+        sj -= rs < 0 ? 1u : 0u;
+        si = stratum - sj * cam.sqrt_spp;
+    } else {
+        i = pixel % cam.W, j = pixel / cam.W;
+        si = stratum % cam.sqrt_spp, sj = stratum / cam.sqrt_spp;
+    }
     float ox = ((float(si) + rng.next()) * cam.inv_sqrt) - 0.5f;
     float oy = ((float(sj) + rng.next()) * cam.inv_sqrt) - 0.5f;
     // px_sample - camera_center, accumulated from small terms so the sub-pixel offset
@@ -978,7 +1037,7 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
             pdf = lights_pdf(sc, p, dir);
         } else {
             // 0.5 light list + 0.5 material PDF (pdf.rs:62-90), intended branch order
-            ONB uvw(n);
+            ONB uvw(n, true);
             bool pick_light = false;
             if (sc.lights_kind != RT_LIGHTS_NONE) pick_light = rng.next() < 0.5f;
             if (pick_light) {

@@ -105,20 +105,12 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Rng &r) {
     }
 }
 
-// vec.rs:246-256
-__device__ __forceinline__ V3 cosine_from(float r1, float r2) {
-    float phi = 2.0f * RT_PI * r1;
-    float s, c;
-    __sincosf(phi, &s, &c);
-    float sr = sqrtf(r2);
-    return {c * sr, s * sr, sqrtf(1.0f - r2)};
-}
-
 // onb.rs:13-45
 struct ONB {
     V3 u, v, w;
-    __device__ __forceinline__ explicit ONB(V3 n) {
-        w = unit(n);
+    // unit_already: n has length 1 to fp32 rounding (a stored normal); onb.rs normalises regardless
+    __device__ __forceinline__ explicit ONB(V3 n, bool unit_already = false) {
+        w = unit_already ? n : unit(n);
         V3 a = fabsf(w.x) > 0.9f ? V3{0.f, 1.f, 0.f} : V3{1.f, 0.f, 0.f};
         v = unit(cross(w, a));
         u = cross(w, v);
