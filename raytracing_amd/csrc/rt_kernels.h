@@ -161,49 +161,52 @@ __device__ __forceinline__ void two_sum(float a, float b, float &s, float &e) {
     float bb = s - a;
     e = (a - (s - bb)) + (b - bb);
 }
+// The compensated arithmetic runs only where c = |oc|^2 - r^2 has lost more than six bits to
+// cancellation: an origin within r/128 of the surface but not on it -- always for objects resting
+// on a ground sphere of radius 1000, rarely otherwise, so most waves skip it.  A ray that starts
+// on the sphere needs neither c nor the low part of centre - o (its root is 2h/a).
 __device__ __forceinline__ bool hit_sphere(float4 s0, float4 s1, V3 o, V3 d, float time, float tlo, float thi,
                                            bool from_self, float &t) {
 #pragma clang fp contract(off) // the error terms below must see the same roundings as the sums
-    V3 center = fma3(mk(s1), time, mk(s0));
-    V3 oc, ol; // oc + ol = centre - o exactly
-    two_sum(center.x, -o.x, oc.x, ol.x);
-    two_sum(center.y, -o.y, oc.y, ol.y);
-    two_sum(center.z, -o.z, oc.z, ol.z);
-    const float r = s0.w;
+    const V3 center = fma3(mk(s1), time, mk(s0));
+    const float r = s0.w, pr = r * r;
     const float a = len2(d);
-    const float h = dot(d, oc) + dot(d, ol);
     const float inv_a = 1.0f / a;
-    float root;
+    V3 oc = center - o;
+    float h = dot(d, oc);
+    const float b2 = len2(oc);
+    float c = b2 - pr;
+    // discriminant about the point of closest approach: disc/a = r^2 - |oc - (h/a) d|^2
+    float disc = a * fmaf(r, r, -len2(fma3(d, -(h * inv_a), oc)));
     if (from_self) {
-        root = 2.0f * h * inv_a;
+        const float root = 2.0f * h * inv_a;
         if (!(tlo < root && root < thi)) return false;
-        // the reference still needs a real discriminant here
-        V3 perp0 = fma3(d, -(h * inv_a), oc);
-        if (fmaf(r, r, -len2(perp0)) < 0.0f) return false;
+        if (disc < 0.0f) return false; // the reference still needs a real discriminant here
         t = root;
         return true;
     }
-    // c = |oc|^2 - r^2, compensated
-    float px = oc.x * oc.x, py = oc.y * oc.y, pz = oc.z * oc.z, pr = r * r;
-    float low = fmaf(oc.x, oc.x, -px) + fmaf(oc.y, oc.y, -py) + fmaf(oc.z, oc.z, -pz) - fmaf(r, r, -pr);
-    low = fmaf(2.0f, dot(oc, ol), low);
-    float s1_, e1, s2_, e2, s3_, e3;
-    two_sum(px, py, s1_, e1);
-    two_sum(s1_, pz, s2_, e2);
-    two_sum(s2_, -pr, s3_, e3);
-    const float c = s3_ + (e1 + e2 + e3 + low);
-    float disc;
-    if (fabsf(c) < pr) {
-        disc = fmaf(h, h, -(a * c));
-    } else {
-        V3 perp = fma3(d, -(h * inv_a), oc) + ol;
-        disc = a * fmaf(r, r, -len2(perp));
+    if (fabsf(c) < 0.015625f * fmaxf(b2, pr)) {
+        V3 ol; // oc + ol = centre - o exactly
+        two_sum(center.x, -o.x, oc.x, ol.x);
+        two_sum(center.y, -o.y, oc.y, ol.y);
+        two_sum(center.z, -o.z, oc.z, ol.z);
+        h = dot(d, oc) + dot(d, ol);
+        // c = |oc|^2 - r^2, compensated
+        float px = oc.x * oc.x, py = oc.y * oc.y, pz = oc.z * oc.z;
+        float low = fmaf(oc.x, oc.x, -px) + fmaf(oc.y, oc.y, -py) + fmaf(oc.z, oc.z, -pz) - fmaf(r, r, -pr);
+        low = fmaf(2.0f, dot(oc, ol), low);
+        float s1_, e1, s2_, e2, s3_, e3;
+        two_sum(px, py, s1_, e1);
+        two_sum(s1_, pz, s2_, e2);
+        two_sum(s2_, -pr, s3_, e3);
+        c = s3_ + (e1 + e2 + e3 + low);
+        disc = fmaf(h, h, -(a * c)); // |c| << r^2 here: this form is the well-conditioned one
     }
     if (disc < 0.0f) return false;
     const float q = h + copysignf(sqrtf(disc), h);
     const float ta = c / q, tb = q * inv_a;
     const float t_near = fminf(ta, tb), t_far = fmaxf(ta, tb);
-    root = t_near;
+    float root = t_near;
     if (!(tlo < root && root < thi)) {
         root = t_far;
         if (!(tlo < root && root < thi)) return false;
