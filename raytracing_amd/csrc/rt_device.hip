@@ -198,7 +198,13 @@ int validate_scene(rt_handle *h, const rt_scene_desc *s) {
     if (s->lights_kind == RT_LIGHTS_SINGLE && s->n_lights != 1)
         return fail(h, "rt_upload_scene: single light needs n_lights == 1");
     for (uint32_t i = 0; i < s->n_lights; ++i)
+    {
         if (!ref_ok(s, s->light_refs[i], false, false)) return fail(h, "rt_upload_scene: light must be a quad or sphere");
+        const uint32_t lr = s->light_refs[i];
+        // only Parallelogram implements pdf_value / random (hittable.rs:377-395)
+        if ((lr >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD && s->quads[lr & RT_REF_INDEX_MASK].shape != RT_SHAPE_PARALLELOGRAM)
+            return fail(h, "rt_upload_scene: a quad light must be a parallelogram");
+    }
     return 0;
 }
 

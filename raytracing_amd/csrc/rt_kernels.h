@@ -706,14 +706,19 @@ template <bool UNIFORM>
 __device__ __forceinline__ float light_pdf(SceneRef sc, uint32_t r, V3 p, V3 dir) {
     uint32_t idx = r & RT_REF_INDEX_MASK;
     if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
+        // a light quad is a Parallelogram (only that shape implements pdf_value, and the upload
+        // of a scene holds lights to it): the plane test of hit_quad without the shape cases
         const float4 *Q = sc.quads + 6 * idx;
-        float t, a, b;
-        if (!hit_quad<UNIFORM>(Q, p, dir, 0.001f, RT_INF, t, a, b)) return 0.0f;
-        float4 q1 = load4<UNIFORM>(Q, 1);
-        float l2 = len2(dir);
-        float dist2 = t * t * l2;
-        float cosine = fabsf(dot(dir, mk(q1))) * rsq(l2);
-        return dist2 * rcp(cosine * q1.w);
+        const float4 q0 = load4<UNIFORM>(Q, 0), q1 = load4<UNIFORM>(Q, 1), q2 = load4<UNIFORM>(Q, 2), q3 = load4<UNIFORM>(Q, 3);
+        const float denom = dot(mk(q1), dir);
+        const V3 qo = mk(q0) - p;
+        const float t = dot(mk(q1), qo) * rcp(denom);
+        const V3 ph = fma3(dir, t, -qo);
+        const float a = dot(ph, mk(q2)), b = dot(ph, mk(q3));
+        const float outside = fmaxf(fmaxf(-a, -b), fmaxf(a, b) - 1.0f);
+        if (!(fmaxf(outside, 0.001f - t) <= 0.0f) || !(fabsf(denom) >= 1e-8f)) return 0.0f;
+        const float l2 = len2(dir);
+        return t * t * l2 * rcp(fabsf(denom) * rsq(l2) * q1.w); // dist^2 / (cosine * area)
     }
     // Only hit or miss matters here, for an origin away from the light: the quadratic about the
     // point of closest approach, disc/a = r^2 - |oc - (h/a) d|^2, without the compensated terms
