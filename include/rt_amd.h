@@ -147,12 +147,19 @@ typedef struct {
     uint32_t sqrt_spp;     /* floor(sqrt(samples_per_px)), camera.rs:341 */
     uint32_t max_depth;
     uint32_t background_sky; /* 1 = Background::Sky (camera.rs:473-482), 0 = Constant */
-    uint32_t pad;
+    uint32_t antialiasing;   /* RT_AA_SQUARE | RT_AA_DISC (AntialiasingType, camera.rs:204-211) */
     double background[3];
     double center[3], pixel_00[3], pxdelta_u[3], pxdelta_v[3];
     double defocus_angle;
     double defocus_disk_u[3], defocus_disk_v[3];
 } rt_camera;
+
+/* AntialiasingType (camera.rs:204-211).  The reference stores it and never reads it
+ * (camera.rs:237): get_ray always samples the stratified square (camera.rs:409-414).  Here
+ * Square is that; Disc does what the reference documents for it -- points from an r = 0.5 px
+ * disc about the pixel centre, drawn by rejection like two_d.rs:183-190, not stratified. */
+#define RT_AA_SQUARE 0u
+#define RT_AA_DISC 1u
 
 #define RT_MODE_REF_EXACT 0u /* estimator exactly as shipped, camera.rs:455-470 */
 #define RT_MODE_BOOK3 1u     /* mixture estimator built from pdf.rs/onb.rs, specular bypass */
@@ -272,6 +279,7 @@ typedef struct { /* CameraBuilder (camera.rs:14-181) */
     uint32_t samples_per_px;
     uint32_t max_depth;
     int32_t background_sky;
+    int32_t antialiasing; /* RT_AA_SQUARE (default) | RT_AA_DISC, CameraBuilder::antialias (camera.rs:114-123) */
     double background[3];
     double center[3], target[3], vup[3];
     double defocus_angle_deg;

@@ -343,7 +343,7 @@ def load_scene(sb, text, base_dir=""):
         return None
     cam = dict(image_width=400, image_height=200, vfov=90.0, samples_per_px=10, max_depth=10, background=None,
                camera_center=(0.0, 0.0, 0.0), camera_target=(0.0, 0.0, -1.0), vup=(0.0, 1.0, 0.0), defocus_angle=0.0,
-               focal_length=1.0)  # camera.rs:183-202
+               focal_length=1.0, antialiasing="square")  # camera.rs:183-202
     for k in ("image_width", "image_height", "samples_per_px", "max_depth"):
         if k in c:
             cam[k] = int(c[k])
@@ -355,6 +355,10 @@ def load_scene(sb, text, base_dir=""):
     for k in ("camera_center", "camera_target", "vup"):
         if k in c:
             cam[k] = vec3(c[k], f"config.camera.{k}")
+    if "antialiasing" in c:
+        if str(c["antialiasing"]).lower() not in ("square", "disc"):
+            raise ConfigError('config.camera.antialiasing must be "square" or "disc".')
+        cam["antialiasing"] = str(c["antialiasing"]).lower()
     if "background" in c:
         b = c["background"]
         cam["background"] = None if isinstance(b, str) and b.upper() == "SKY" else color_ext(b, "config.camera.background")

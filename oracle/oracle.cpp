@@ -837,6 +837,7 @@ struct Camera {
     uint32_t samples_per_px, sqrt_spp, max_depth;
     double px_sample_scale, sqrt_spp_scale, defocus_angle;
     bool sky;
+    bool aa_disc = false;
     Color bg;
 
     explicit Camera(const orc_camera &b) { // camera.rs:280-366
@@ -870,12 +871,23 @@ struct Camera {
         sqrt_spp_scale = 1.0 / double(sqrt_spp);
         max_depth = b.max_depth;
         sky = b.background_sky != 0;
+        aa_disc = b.antialiasing == 1;
         bg = {b.background[0], b.background[1], b.background[2]};
     }
 
     Ray get_ray(uint32_t i, uint32_t j, uint32_t si, uint32_t sj, Ctx &c) const { // camera.rs:409-430
-        double ox = ((double(si) + c.rng.next()) * sqrt_spp_scale) - 0.5;
-        double oy = ((double(sj) + c.rng.next()) * sqrt_spp_scale) - 0.5;
+        double ox, oy;
+        if (aa_disc) { // documented at camera.rs:209-210, drawn like two_d.rs:183-190
+            for (;;) {
+                ox = c.rng.range_pm1();
+                oy = c.rng.range_pm1();
+                if (ox * ox + oy * oy < 1.0) break;
+            }
+            ox *= 0.5, oy *= 0.5;
+        } else {
+            ox = ((double(si) + c.rng.next()) * sqrt_spp_scale) - 0.5;
+            oy = ((double(sj) + c.rng.next()) * sqrt_spp_scale) - 0.5;
+        }
         V3 px_sample = pixel_00 + (double(i) + ox) * pxdelta_u + (double(j) + oy) * pxdelta_v;
         V3 origin = center;
         if (!(defocus_angle <= 0.0)) { // camera.rs:484-488, two_d.rs:183-190

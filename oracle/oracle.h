@@ -45,6 +45,9 @@ typedef struct {
     uint32_t samples_per_px; /* requested; floor(sqrt)^2 is rendered (camera.rs:341-342) */
     uint32_t max_depth;
     int32_t background_sky; /* 1 = Background::Sky, 0 = Constant(background) */
+    int32_t antialiasing;   /* 0 = Square: what get_ray does (camera.rs:409-414); 1 = Disc: r = 0.5 px disc
+                             * about the pixel centre as AntialiasingType documents it (camera.rs:204-211),
+                             * which the reference never implemented -- parity unpinned */
     double background[3];
     double center[3], target[3], vup[3];
     double defocus_angle_deg;

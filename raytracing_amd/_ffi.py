@@ -58,7 +58,7 @@ class RtSceneDesc(C.Structure):
 
 class RtCamera(C.Structure):
     _fields_ = [("image_width", u32), ("image_height", u32), ("sqrt_spp", u32), ("max_depth", u32),
-                ("background_sky", u32), ("pad", u32), ("background", f64 * 3), ("center", f64 * 3),
+                ("background_sky", u32), ("antialiasing", u32), ("background", f64 * 3), ("center", f64 * 3),
                 ("pixel_00", f64 * 3), ("pxdelta_u", f64 * 3), ("pxdelta_v", f64 * 3), ("defocus_angle", f64),
                 ("defocus_disk_u", f64 * 3), ("defocus_disk_v", f64 * 3)]
 
@@ -76,7 +76,7 @@ class RtStats(C.Structure):
 class CameraBuilderStruct(C.Structure):
     """Field layout shared by rth_camera_builder and the oracle's camera struct."""
     _fields_ = [("image_width", u32), ("image_height", u32), ("vfov_deg", f64), ("samples_per_px", u32),
-                ("max_depth", u32), ("background_sky", i32), ("background", f64 * 3), ("center", f64 * 3),
+                ("max_depth", u32), ("background_sky", i32), ("antialiasing", i32), ("background", f64 * 3), ("center", f64 * 3),
                 ("target", f64 * 3), ("vup", f64 * 3), ("defocus_angle_deg", f64), ("focal_length", f64)]
 
 

@@ -187,6 +187,7 @@ class CameraSettings:
     vup: Sequence[float] = (0.0, 1.0, 0.0)
     defocus_angle: float = 0.0
     focal_length: float = 1.0
+    antialiasing: str = "square"  # AntialiasingType (camera.rs:204-211): "square" | "disc"
 
     def with_aspect_ratio(self, width, aspect_ratio):
         """camera.rs:78-92"""
@@ -214,6 +215,7 @@ class CameraSettings:
             b.center[i] = self.camera_center[i]
             b.target[i] = self.camera_target[i]
             b.vup[i] = self.vup[i]
+        b.antialiasing = {"square": 0, "disc": 1}[self.antialiasing]
         b.defocus_angle_deg = self.defocus_angle
         b.focal_length = self.focal_length
         return b

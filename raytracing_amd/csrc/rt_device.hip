@@ -238,6 +238,7 @@ int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCa
     d.max_depth = c->max_depth;
     d.defocus = !(c->defocus_angle <= 0.0); // camera.rs:422
     d.sky = c->background_sky != 0;
+    d.aa_disc = c->antialiasing == RT_AA_DISC;
     *out = d;
     *se = e;
     // the kernels read the camera from device memory

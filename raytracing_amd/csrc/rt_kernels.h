@@ -62,7 +62,7 @@ enum : int { ACCEL_FLAT = 0, ACCEL_BVH2 = 1, ACCEL_BVH4 = 2 };
 
 struct DCamera {
     V3 p00_rel, du, dv, center, disk_u, disk_v, bg;
-    uint32_t W, H, npix, sqrt_spp, stratum_begin, max_depth, defocus, sky;
+    uint32_t W, H, npix, sqrt_spp, stratum_begin, max_depth, defocus, sky, aa_disc;
     float inv_sqrt, inv_w;
 };
 
@@ -770,8 +770,18 @@ __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t 
         i = pixel % cam.W, j = pixel / cam.W;
         si = stratum % cam.sqrt_spp, sj = stratum / cam.sqrt_spp;
     }
-    float ox = ((float(si) + rng.next()) * cam.inv_sqrt) - 0.5f;
-    float oy = ((float(sj) + rng.next()) * cam.inv_sqrt) - 0.5f;
+    float ox, oy;
+    if (cam.aa_disc) { // AntialiasingType::Disc: r = 0.5 px about the pixel centre, not stratified
+        for (;;) {
+            ox = rng.pm1();
+            oy = rng.pm1();
+            if (ox * ox + oy * oy < 1.0f) break;
+        }
+        ox *= 0.5f, oy *= 0.5f;
+    } else { // camera.rs:411-412
+        ox = ((float(si) + rng.next()) * cam.inv_sqrt) - 0.5f;
+        oy = ((float(sj) + rng.next()) * cam.inv_sqrt) - 0.5f;
+    }
     // px_sample - camera_center, accumulated from small terms so the sub-pixel offset
     // survives fp32 (pixel_00 itself sits at scene-scale coordinates)
     V3 rel = fma3(ldv(cam.du), float(i), ldv(cam.p00_rel));

@@ -792,6 +792,12 @@ SceneFile load_scene_file(const std::string &text, const std::string &base_dir, 
         vec("vup", c.vup, "vector");
         num("defocus_angle", c.defocus_angle_deg);
         num("focal_length", c.focal_length);
+        auto aa = ct->find("antialiasing"); // AntialiasingType (camera.rs:204-211)
+        if (aa != ct->end()) {
+            const std::string v = aa->second.type == Value::STRING ? upper(aa->second.s) : "";
+            if (v != "SQUARE" && v != "DISC") throw Error(base + ".antialiasing must be \"square\" or \"disc\".");
+            c.antialiasing = v == "DISC" ? int32_t(RT_AA_DISC) : int32_t(RT_AA_SQUARE);
+        }
         auto bg = ct->find("background");
         if (bg != ct->end()) {
             if (bg->second.type == Value::STRING && upper(bg->second.s) == "SKY") {

@@ -88,7 +88,7 @@ int rth_camera_build(const rth_camera_builder *b, rt_camera *out, char *err, uin
     CameraBuilder cb;
     cb.dimensions(b->image_width, b->image_height)
         .max_depth(b->max_depth)
-        .antialias(AntialiasingType::Square, b->samples_per_px)
+        .antialias(b->antialiasing == int32_t(RT_AA_DISC) ? AntialiasingType::Disc : AntialiasingType::Square, b->samples_per_px)
         .focal_length(b->focal_length)
         .vfov(b->vfov_deg)
         .defocus_angle(b->defocus_angle_deg)

@@ -286,9 +286,10 @@ CameraBuilder &CameraBuilder::background(Background bg) {
     b.background[0] = bg.color.r, b.background[1] = bg.color.g, b.background[2] = bg.color.b;
     return *this;
 }
-CameraBuilder &CameraBuilder::antialias(AntialiasingType, uint32_t spp) {
+CameraBuilder &CameraBuilder::antialias(AntialiasingType type, uint32_t spp) {
     add_err(errors, spp < 1, "antialias: Invalid samples_per_px: must be at least 1, found " + std::to_string(spp));
     b.samples_per_px = spp;
+    b.antialiasing = type == AntialiasingType::Disc ? int32_t(RT_AA_DISC) : int32_t(RT_AA_SQUARE);
     return *this;
 }
 CameraBuilder &CameraBuilder::camera_center(Point3 c) {
@@ -357,6 +358,7 @@ Camera Camera::build(const rth_camera_builder &b) { // camera.rs:280-366
     c.sqrt_spp = sqrt_spp;
     c.max_depth = b.max_depth;
     c.background_sky = b.background_sky ? 1u : 0u;
+    c.antialiasing = b.antialiasing == int32_t(RT_AA_DISC) ? RT_AA_DISC : RT_AA_SQUARE;
     auto put = [](double *dst, Vec3 s) { dst[0] = s.x, dst[1] = s.y, dst[2] = s.z; };
     put(c.background, {b.background[0], b.background[1], b.background[2]});
     put(c.center, center);

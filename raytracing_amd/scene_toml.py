@@ -23,6 +23,7 @@ def camera_from_struct(b) -> CameraSettings:
     cam.background = None if b.background_sky else tuple(b.background)
     cam.camera_center, cam.camera_target, cam.vup = tuple(b.center), tuple(b.target), tuple(b.vup)
     cam.defocus_angle, cam.focal_length = b.defocus_angle_deg, b.focal_length
+    cam.antialiasing = "disc" if b.antialiasing == 1 else "square"
     return cam
 
 
@@ -272,6 +273,8 @@ class TomlRecorder:
             out.append(f"samples_per_px = {cam.samples_per_px}\nmax_depth = {cam.max_depth}\nvfov = {_num(cam.vfov)}")
             out.append(f"camera_center = {_vec(cam.camera_center)}\ncamera_target = {_vec(cam.camera_target)}\nvup = {_vec(cam.vup)}")
             out.append(f"defocus_angle = {_num(cam.defocus_angle)}\nfocal_length = {_num(cam.focal_length)}")
+            if cam.antialiasing != "square":
+                out.append(f'antialiasing = "{cam.antialiasing}"')
             out.append('background = "sky"\n' if cam.background is None else f"background = {_vec(cam.background)}\n")
         if self.light_list:
             out.insert(1, "light_list = true\n")

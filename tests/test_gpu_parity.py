@@ -179,6 +179,42 @@ def test_render_with_other_acceleration_structures(device, name, builder, width)
     assert off.mean() < 0.01, off.mean()  # ties and separately compiled kernels fork a few paths
 
 
+def test_antialiasing_disc_camera_rays_and_render(device):
+    """AntialiasingType::Disc (documented at camera.rs:209-210, never read by the reference:
+    parity pinned by the oracle only).  Device and oracle draw the same disc offsets; the
+    offsets lie within 0.5 px of the pixel centre; a render agrees pixel by pixel."""
+    host, osb, cam, mode, _ = scene("c2", device)  # with defocus: disc draws, then the defocus disk, then time
+    disc = ra.CameraSettings(**{**cam.__dict__, "antialiasing": "disc"})
+    rng = np.random.default_rng(2)
+    n = 20000
+    pix = rng.integers(0, cam.image_width * cam.image_height, n).astype(np.uint32)
+    strat = rng.integers(0, cam.effective_spp, n).astype(np.uint32)
+    o, d, t = device.camera_rays(disc.build(), pix, strat, seed=9)
+    oo, dd, tt = orc.camera_rays(osb, disc, pix, strat, seed=9)
+    scale = np.abs(dd).max()
+    bad = (np.abs(d - dd).max(axis=1) > 2e-6 * scale) | (np.abs(o - oo).max(axis=1) > 1e-5 * (np.abs(oo).max() + 1))
+    assert bad.mean() < 2e-3, bad.sum()  # two rejection loops: a few more edge decisions than with one
+    # offsets: without defocus the ray passes through pixel_00 + (i + ox) du + (j + oy) dv
+    sharp = ra.CameraSettings(**{**disc.__dict__, "defocus_angle": 0.0})
+    rcs = sharp.build()
+    o2, d2, _ = orc.camera_rays(osb, sharp, pix, strat, seed=9)
+    du, dv, p00, c = (np.array(list(x)) for x in (rcs.pxdelta_u, rcs.pxdelta_v, rcs.pixel_00, rcs.center))
+    rel = o2 + d2 - p00  # = (i + ox) du + (j + oy) dv
+    ij = np.stack([rel @ du / (du @ du), rel @ dv / (dv @ dv)], axis=1)
+    off = ij - np.stack([pix % cam.image_width, pix // cam.image_width], axis=1)
+    r = np.linalg.norm(off, axis=1)
+    assert r.max() < 0.5 + 1e-9 and 0.3 < r.mean() < 0.36  # uniform in the disc: E[r] = 1/3
+    assert np.abs(off.mean(axis=0)).max() < 0.01
+    device.film_resize(cam.image_width, cam.image_height)
+    device.render(disc.build(), mode=mode, seed=5)
+    gpu = device.film(1.0 / cam.effective_spp)
+    film, _, _ = orc.render(osb, disc, mode=mode, seed=5)
+    rr = helpers.compare_same_stream(gpu, film / cam.effective_spp)
+    assert rr["median_rel"] < 1e-4 and rr["frac_5e2"] < 0.08, rr
+    device.render(cam.build(), mode=mode, seed=5)  # the square sampler gives another image
+    assert not np.allclose(device.film(0.5 / cam.effective_spp), gpu, rtol=1e-3)
+
+
 def sphere_ids(host):
     d = host.flatten().contents
     return np.array([d.spheres[i].prim_id for i in range(d.n_spheres)], dtype=np.int64)

@@ -506,6 +506,20 @@ def test_wide_bvh_is_a_regrouping_of_the_descriptor(name):
     desc.contents.root = saved
 
 
+def test_scene_file_camera_antialiasing_round_trip():
+    from raytracing_amd import scene_toml
+    rec = scene_toml.TomlRecorder()
+    cam = ra.scenes.cornell_main(rec, width=32, spp=4)
+    cam.antialiasing = "disc"
+    text = rec.dumps(cam)
+    assert 'antialiasing = "disc"' in text
+    assert scene_toml.load_scene(ra.SceneBuilder(), text) == cam
+    assert ra.CameraSettings(**config_oracle.load_scene(orc.scene(), text)) == cam
+    assert cam.build().antialiasing == 1 and ra.CameraSettings().build().antialiasing == 0
+    with pytest.raises(ra.RtError, match="square"):
+        scene_toml.load_scene(ra.SceneBuilder(), text.replace('"disc"', '"hexagon"'))
+
+
 def test_committed_scene_files_load():
     from raytracing_amd import scene_toml
     root = Path(ra.__file__).resolve().parent.parent / "scenes"
