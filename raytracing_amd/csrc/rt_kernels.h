@@ -23,6 +23,10 @@ constexpr int WAVE = 64;
 constexpr int BLOCK = 256;          // 4 waves = 4 chunks per block
 constexpr int STACK_DEPTH = 32;     // per-lane traversal stack entries (LDS)
 constexpr int LDS_NODES = 128;      // BVH nodes staged per block (8 KiB)
+#ifndef RT_NODE_QUORUM
+#define RT_NODE_QUORUM 16
+#endif
+constexpr uint32_t NODE_QUORUM = RT_NODE_QUORUM; // see traverse4
 
 // Read-only scene records through the constant address space: with a wave-uniform address the
 // backend selects scalar loads (s_load_dwordx4..x16), the record lands in SGPRs and feeds the
@@ -420,7 +424,15 @@ __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, f
     uint32_t sp = 0;
     uint32_t cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
     for (;;) {
-        while ((cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) {
+        // Node steps run while at least NODE_QUORUM lanes of the wave are at a node (or no lane
+        // holds a primitive); then the lanes that hold a primitive test it while the few node
+        // lanes wait.  Waiting for the last node lane instead (quorum 1) idles most of the wave.
+        for (;;) {
+            const bool at_node = (cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE;
+            const uint32_t n_node = uint32_t(__popcll(__ballot(at_node)));
+            if (n_node == 0) break;
+            if (n_node < NODE_QUORUM && __ballot(!at_node && cur != RT_REF_NONE) != 0) break;
+            if (!at_node) continue;
             const uint32_t nb = (cur & RT_REF_INDEX_MASK) * 128u; // the wide array stays below 4 GiB (checked at upload)
             const char *node = (STAGED && nb < lds_bytes ? l_nodes : g_nodes) + nb;
             auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(node + byte_off); };
@@ -468,10 +480,11 @@ __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, f
                 cur = RT_REF_NONE;
             }
         }
-        if (cur == RT_REF_NONE) break;
-        test_prim(sc, cur, o, d, time, tlo, origin_ref, rc, best);
-        if (sp == 0) break;
-        cur = stack[(--sp) * BLOCK];
+        if (__ballot(cur != RT_REF_NONE) == 0) break; // every lane of the wave is done
+        if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
+            test_prim(sc, cur, o, d, time, tlo, origin_ref, rc, best);
+            cur = sp ? stack[(--sp) * BLOCK] : RT_REF_NONE;
+        }
     }
 }
 
