@@ -26,7 +26,11 @@ constexpr int LDS_NODES = 128;      // BVH nodes staged per block (8 KiB)
 #ifndef RT_NODE_QUORUM
 #define RT_NODE_QUORUM 16
 #endif
-constexpr uint32_t NODE_QUORUM = RT_NODE_QUORUM; // see traverse4
+constexpr uint32_t NODE_QUORUM = RT_NODE_QUORUM; // see trav4_round
+#ifndef RT_SHADE_QUORUM
+#define RT_SHADE_QUORUM 48
+#endif
+constexpr uint32_t SHADE_QUORUM = RT_SHADE_QUORUM; // see k_paths
 
 // Read-only scene records through the constant address space: with a wave-uniform address the
 // backend selects scalar loads (s_load_dwordx4..x16), the record lands in SGPRs and feeds the
@@ -401,15 +405,23 @@ __device__ __forceinline__ void stage_nodes4(SceneRef sc, uint32_t *s_dyn) {
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) dst[i] = sc.nodes4[i];
     __syncthreads();
 }
+// Wide traversal, resumable.  A lane's traversal is (cur, sp, best): cur is the node or primitive
+// it handles next (RT_REF_NONE: none -- finished, or not traversing), sp its LDS stack height.
+// One round = node steps while enough lanes are at nodes, then one primitive test for the lanes
+// that hold one.  Lanes with cur == RT_REF_NONE take no part.
 // STAGED = false reads every node from global memory with plain global loads (generic loads
 // cost ~13 % on a scene too deep to leave LDS for nodes).
-template <bool STAGED>
-__device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
-                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *s_dyn, Best &best) {
-    uint32_t *stack = s_dyn + threadIdx.x;
+__device__ __forceinline__ void trav4_begin(float thi, uint32_t &cur, uint32_t &sp, Best &best) {
     best.t = thi;
     best.ref = best.mat = RT_REF_NONE;
     best.u = best.v = 0.f;
+    sp = 0;
+    cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
+}
+template <bool STAGED>
+__device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
+                                            const RayCtx &rc, uint32_t *s_dyn, uint32_t &cur, uint32_t &sp, Best &best) {
+    uint32_t *stack = s_dyn + threadIdx.x;
     typedef float v2f __attribute__((ext_vector_type(2))); // two children per packed instruction
     const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const v2f ix = {rcp(d.x), rcp(d.x)}, iy = {rcp(d.y), rcp(d.y)}, iz = {rcp(d.z), rcp(d.z)};
@@ -421,71 +433,75 @@ __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, f
     const char *g_nodes = reinterpret_cast<const char *>(sc.nodes4);
     const char *l_nodes = reinterpret_cast<const char *>(s_dyn + size_t(sc.stack4) * BLOCK);
     const uint32_t lds_bytes = sc.lds_nodes4 * 128u;
-    uint32_t sp = 0;
-    uint32_t cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
+    // Node steps run while at least NODE_QUORUM lanes of the wave are at a node (or no lane
+    // holds a primitive); then the lanes that hold a primitive test it while the few node
+    // lanes wait.  Waiting for the last node lane instead (quorum 1) idles most of the wave.
     for (;;) {
-        // Node steps run while at least NODE_QUORUM lanes of the wave are at a node (or no lane
-        // holds a primitive); then the lanes that hold a primitive test it while the few node
-        // lanes wait.  Waiting for the last node lane instead (quorum 1) idles most of the wave.
-        for (;;) {
-            const bool at_node = (cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE;
-            const uint32_t n_node = uint32_t(__popcll(__ballot(at_node)));
-            if (n_node == 0) break;
-            if (n_node < NODE_QUORUM && __ballot(!at_node && cur != RT_REF_NONE) != 0) break;
-            if (!at_node) continue;
-            const uint32_t nb = (cur & RT_REF_INDEX_MASK) * 128u; // the wide array stays below 4 GiB (checked at upload)
-            const char *node = (STAGED && nb < lds_bytes ? l_nodes : g_nodes) + nb;
-            auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(node + byte_off); };
-            const float4 ax = ld(nx), ay = ld(ny), az = ld(nz);
-            const float4 bx = ld(fx), by = ld(fy), bz = ld(fz);
-            const float4 cf = ld(96u);
-            uint32_t ref[4] = {fbits(cf.x), fbits(cf.y), fbits(cf.z), fbits(cf.w)};
-            // BoundingBox3::hit (boundingbox.rs:96-113) for four boxes; see hit_box for the slack.
-            // 0 * inf = NaN where the origin lies on a plane the ray is parallel to: max3/min3
-            // drop NaN operands, which leaves that axis unconstrained.
-            const v2f nx01 = (v2f{ax.x, ax.y} - ox) * ix, nx23 = (v2f{ax.z, ax.w} - ox) * ix;
-            const v2f ny01 = (v2f{ay.x, ay.y} - oy) * iy, ny23 = (v2f{ay.z, ay.w} - oy) * iy;
-            const v2f nz01 = (v2f{az.x, az.y} - oz) * iz, nz23 = (v2f{az.z, az.w} - oz) * iz;
-            const v2f fx01 = (v2f{bx.x, bx.y} - ox) * ix, fx23 = (v2f{bx.z, bx.w} - ox) * ix;
-            const v2f fy01 = (v2f{by.x, by.y} - oy) * iy, fy23 = (v2f{by.z, by.w} - oy) * iy;
-            const v2f fz01 = (v2f{bz.x, bz.y} - oz) * iz, fz23 = (v2f{bz.z, bz.w} - oz) * iz;
-            const float tn[4] = {fmaxf(fmaxf(fmaxf(nx01.x, ny01.x), nz01.x), tlo), fmaxf(fmaxf(fmaxf(nx01.y, ny01.y), nz01.y), tlo),
-                                 fmaxf(fmaxf(fmaxf(nx23.x, ny23.x), nz23.x), tlo), fmaxf(fmaxf(fmaxf(nx23.y, ny23.y), nz23.y), tlo)};
-            const float tf[4] = {fminf(fminf(fminf(fx01.x, fy01.x), fz01.x), best.t), fminf(fminf(fminf(fx01.y, fy01.y), fz01.y), best.t),
-                                 fminf(fminf(fminf(fx23.x, fy23.x), fz23.x), best.t), fminf(fminf(fminf(fx23.y, fy23.y), fz23.y), best.t)};
-            uint32_t key[4];
+        const bool at_node = (cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE;
+        const uint32_t n_node = uint32_t(__popcll(__ballot(at_node)));
+        if (n_node == 0) break;
+        if (n_node < NODE_QUORUM && __ballot(!at_node && cur != RT_REF_NONE) != 0) break;
+        if (!at_node) continue;
+        const uint32_t nb = (cur & RT_REF_INDEX_MASK) * 128u; // the wide array stays below 4 GiB (checked at upload)
+        const char *node = (STAGED && nb < lds_bytes ? l_nodes : g_nodes) + nb;
+        auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(node + byte_off); };
+        const float4 ax = ld(nx), ay = ld(ny), az = ld(nz);
+        const float4 bx = ld(fx), by = ld(fy), bz = ld(fz);
+        const float4 cf = ld(96u);
+        uint32_t ref[4] = {fbits(cf.x), fbits(cf.y), fbits(cf.z), fbits(cf.w)};
+        // BoundingBox3::hit (boundingbox.rs:96-113) for four boxes; see hit_box for the slack.
+        // 0 * inf = NaN where the origin lies on a plane the ray is parallel to: max3/min3
+        // drop NaN operands, which leaves that axis unconstrained.
+        const v2f nx01 = (v2f{ax.x, ax.y} - ox) * ix, nx23 = (v2f{ax.z, ax.w} - ox) * ix;
+        const v2f ny01 = (v2f{ay.x, ay.y} - oy) * iy, ny23 = (v2f{ay.z, ay.w} - oy) * iy;
+        const v2f nz01 = (v2f{az.x, az.y} - oz) * iz, nz23 = (v2f{az.z, az.w} - oz) * iz;
+        const v2f fx01 = (v2f{bx.x, bx.y} - ox) * ix, fx23 = (v2f{bx.z, bx.w} - ox) * ix;
+        const v2f fy01 = (v2f{by.x, by.y} - oy) * iy, fy23 = (v2f{by.z, by.w} - oy) * iy;
+        const v2f fz01 = (v2f{bz.x, bz.y} - oz) * iz, fz23 = (v2f{bz.z, bz.w} - oz) * iz;
+        const float tn[4] = {fmaxf(fmaxf(fmaxf(nx01.x, ny01.x), nz01.x), tlo), fmaxf(fmaxf(fmaxf(nx01.y, ny01.y), nz01.y), tlo),
+                             fmaxf(fmaxf(fmaxf(nx23.x, ny23.x), nz23.x), tlo), fmaxf(fmaxf(fmaxf(nx23.y, ny23.y), nz23.y), tlo)};
+        const float tf[4] = {fminf(fminf(fminf(fx01.x, fy01.x), fz01.x), best.t), fminf(fminf(fminf(fx01.y, fy01.y), fz01.y), best.t),
+                             fminf(fminf(fminf(fx23.x, fy23.x), fz23.x), best.t), fminf(fminf(fminf(fx23.y, fy23.y), fz23.y), best.t)};
+        uint32_t key[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool hit = (tn[i] <= fmaf(fabsf(tf[i]), BOX_SLACK, tf[i])) & (ref[i] != RT_REF_NONE);
-                key[i] = hit ? fbits(tn[i]) : 0xFFFFFFFFu; // tn >= tlo > 0: float order = unsigned order
-            }
-            // sort the four (key, ref) pairs ascending: 5 compare-exchanges
+        for (int i = 0; i < 4; ++i) {
+            const bool hit = (tn[i] <= fmaf(fabsf(tf[i]), BOX_SLACK, tf[i])) & (ref[i] != RT_REF_NONE);
+            key[i] = hit ? fbits(tn[i]) : 0xFFFFFFFFu; // tn >= tlo > 0: float order = unsigned order
+        }
+        // sort the four (key, ref) pairs ascending: 5 compare-exchanges
 #define RT_CSWAP(a, b)                                                                       \
-    {                                                                                        \
-        const bool sw = key[b] < key[a];                                                     \
-        const uint32_t ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                 \
-        const uint32_t ra_ = sw ? ref[b] : ref[a], rb_ = sw ? ref[a] : ref[b];               \
-        key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                                \
-    }
-            RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+{                                                                                        \
+    const bool sw = key[b] < key[a];                                                     \
+    const uint32_t ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                 \
+    const uint32_t ra_ = sw ? ref[b] : ref[a], rb_ = sw ? ref[a] : ref[b];               \
+    key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                                \
+}
+        RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-            if (key[3] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[3];
-            if (key[2] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[2];
-            if (key[1] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[1];
-            if (key[0] != 0xFFFFFFFFu) {
-                cur = ref[0];
-            } else if (sp) {
-                cur = stack[(--sp) * BLOCK];
-            } else {
-                cur = RT_REF_NONE;
-            }
-        }
-        if (__ballot(cur != RT_REF_NONE) == 0) break; // every lane of the wave is done
-        if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
-            test_prim(sc, cur, o, d, time, tlo, origin_ref, rc, best);
-            cur = sp ? stack[(--sp) * BLOCK] : RT_REF_NONE;
+        if (key[3] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[3];
+        if (key[2] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[2];
+        if (key[1] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[1];
+        if (key[0] != 0xFFFFFFFFu) {
+            cur = ref[0];
+        } else if (sp) {
+            cur = stack[(--sp) * BLOCK];
+        } else {
+            cur = RT_REF_NONE;
         }
     }
+    if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
+        test_prim(sc, cur, o, d, time, tlo, origin_ref, rc, best);
+        cur = sp ? stack[(--sp) * BLOCK] : RT_REF_NONE;
+    }
+}
+
+template <bool STAGED>
+__device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
+                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *s_dyn, Best &best) {
+    uint32_t cur, sp;
+    trav4_begin(thi, cur, sp, best);
+    while (__ballot(cur != RT_REF_NONE) != 0) // until every lane of the wave is done
+        trav4_round<STAGED>(sc, o, d, time, tlo, origin_ref, rc, s_dyn, cur, sp, best);
 }
 
 // One entry for the three structures.  s_stack / s_nodes: static LDS of the binary traversal;
@@ -1199,25 +1215,54 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     bool alive = false; // this lane holds a ray to trace
     float4 ra = {}, rb = {}, sa = {};
     uint2 sb = {};
+    // Wide BVH only: a lane's traversal is resumable (trav4_round), so the wave does not wait for
+    // its slowest ray before shading: once SHADE_QUORUM lanes have something to shade or a sample
+    // to take, they do, and join the lanes still traversing afterwards.  Traversal lengths are
+    // heavy-tailed; waiting for the last lane left 12 % of the lanes active on a large scene.
+    uint32_t cur = RT_REF_NONE, sp = 0; // cur != RT_REF_NONE: this lane is inside a traversal
+    Best best;
+    best.t = RT_INF, best.ref = best.mat = RT_REF_NONE, best.u = best.v = 0.f;
     for (;;) {
-        // 1. closest hit, then what the hit itself contributes (background, emission)
-        const unsigned long long live = __ballot(alive);
-        if (live == 0 && exhausted) break;
-        n_seg += uint32_t(__popcll(live));
         bool scatter = false; // the path goes on from a surface
+        bool busy = false;    // (wide BVH) this lane is inside a traversal and skips the shading steps
         Surface sf;
-        if (alive) {
-            RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
-            Best best;
-            closest_hit<ACCEL, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack, s_nodes, s_dyn, best);
-            scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
-                                 best.mat, sf);
+        if constexpr (ACCEL == ACCEL_BVH4) {
+            busy = alive && cur != RT_REF_NONE;
+            const uint32_t n_busy = uint32_t(__popcll(__ballot(busy)));
+            // lanes with something to do in the shading steps: a finished traversal, or an empty
+            // lane while samples are left
+            const uint32_t n_work = uint32_t(__popcll(__ballot(!busy && (alive || !exhausted))));
+            if (n_busy != 0 && n_work < SHADE_QUORUM) {
+                if (busy) {
+                    RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
+                    if (sc.lds_nodes4) // uniform
+                        trav4_round<true>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, s_dyn, cur, sp, best);
+                    else
+                        trav4_round<false>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, s_dyn, cur, sp, best);
+                }
+                continue;
+            }
+            if (__ballot(alive) == 0 && exhausted) break;
+            if (alive && !busy)
+                scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
+                                     RT_REF_NONE, sf);
+        } else {
+            // 1. closest hit, then what the hit itself contributes (background, emission)
+            const unsigned long long live = __ballot(alive);
+            if (live == 0 && exhausted) break;
+            n_seg += uint32_t(__popcll(live));
+            if (alive) {
+                RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
+                closest_hit<ACCEL, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack, s_nodes, s_dyn, best);
+                scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
+                                     best.mat, sf);
+            }
         }
         // 2. idle lanes take new samples
         bool fresh = false;
-        const unsigned long long idle = __ballot(!scatter);
+        const unsigned long long idle = __ballot(!scatter && !busy);
         const uint32_t n_idle = uint32_t(__popcll(idle));
-        if (!exhausted && (n_idle >= refill_min || n_idle == WAVE)) {
+        if (!exhausted && (n_idle >= refill_min || n_idle == WAVE || (ACCEL == ACCEL_BVH4 && n_idle != 0))) {
             if (next == end) {
                 // guided self-scheduling: ranges shrink with the work that is left (estimated
                 // from the counter value this wave saw last), so the last waves finish together
@@ -1237,7 +1282,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
             const uint32_t prefix =
                 __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
             const unsigned long long g = next + prefix;
-            if (!scatter && g < end) {
+            if (!scatter && !busy && g < end) {
                 uint32_t px = next_pixel + prefix, st = next_stratum;
                 while (px >= cam.npix) px -= cam.npix, ++st;
                 sa.w = bitsf(px);
@@ -1264,8 +1309,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
             alive = true;
         } else if (scatter) {
             alive = shade_scatter<MODE>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
-        } else {
+        } else if (!busy) {
             alive = false;
+        }
+        if constexpr (ACCEL == ACCEL_BVH4) { // lanes with a new ray start its traversal
+            const bool start = alive && !busy;
+            n_seg += uint32_t(__popcll(__ballot(start)));
+            if (start) trav4_begin(RT_INF, cur, sp, best);
         }
     }
     if (lane == 0) {
