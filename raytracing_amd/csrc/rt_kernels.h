@@ -1,8 +1,13 @@
-// rt_kernels.h -- wavefront path-tracing kernels for gfx950 (fp32).
+// rt_kernels.h -- path-tracing kernels for gfx950 (fp32).
 //
-// Replaces the body of Camera::render (camera.rs:386-401) and everything below it.
+// Replaces the body of Camera::render (camera.rs:386-401) and everything below it.  Two
+// pipelines share the intersection, camera, light and material code in this file:
+//   * k_paths (default): one persistent launch per frame; a lane carries one path in registers
+//     from its camera ray to its end and then takes the next (pixel, stratum) sample.  No ray
+//     state goes through memory; see the comment above k_paths.
+//   * the ray-queue pipeline (RT_FLAG_WAVEFRONT), four kernels per iteration, described next.
 //
-// Work layout: the ray pool is split into CHUNKS, one per wavefront.  A chunk holds up to
+// Ray-queue work layout: the ray pool is split into CHUNKS, one per wavefront.  A chunk holds up to
 // `cap` rays, dense at its front; its wave walks it in tiles of 64.  Because a wave owns its
 // chunk, stream compaction after shading is a ballot + mbcnt prefix inside the wave with no
 // atomics and no barriers, and survivors are written in place (writes never pass the tile

@@ -4,6 +4,9 @@
   assets/new-cornell.png (600x600 linear PNG written by its PngWriter): 20x20 block means of
   the 8-bit values / 255.  Needs /root/reference; skipped when it is absent.
 * the rest are outputs of the CPU oracle (oracle/liboracle.so) on fixed seeds.
+* c?_oracle_64x64_converged.npz: the 64x64 frame at 16384 spp (128^2 strata), plus the oracle's
+  own RMSE against it at 256 spp for three seeds of the device's generator (so a device render
+  with the same seed can be held to "no worse than 1.1x the CPU render at equal spp").
 """
 import sys
 from pathlib import Path
@@ -33,6 +36,17 @@ def main():
         np.save(HERE / f"{name}_oracle_64x64_spp16.npy", (film / cam.effective_spp).astype(np.float32))
         o, d, tm, frm = helpers.ray_batch(osb, cam, 4096, seed=7, bbox=((0, 0, 0), (555, 555, 555)))
         hit, prim, t, u, v, t2 = orc.intersect_batch(osb, o, d, tm)
+        conv_cam = ra.CameraSettings(**{**cam.__dict__, "samples_per_px": 16384})
+        conv, _, _ = orc.render(osb, conv_cam, mode=mode, rng=orc.RNG_PHILOX53, seed=99, threads=8)
+        conv = conv / conv_cam.effective_spp
+        cam256 = ra.CameraSettings(**{**cam.__dict__, "samples_per_px": 256})
+        seeds, rmse = [11, 12, 13], []
+        for sd in seeds:
+            f256, _, _ = orc.render(osb, cam256, mode=mode, seed=sd, threads=8)
+            rmse.append(float(np.sqrt(np.mean((f256 / cam256.effective_spp - conv) ** 2))))
+        np.savez_compressed(HERE / f"{name}_oracle_64x64_converged.npz", image=conv.astype(np.float32), spp=np.array([16384]),
+                            seeds=np.array(seeds), rmse_at_256spp=np.array(rmse))
+        print(name, "converged; oracle rmse at 256 spp", rmse)
         np.savez_compressed(HERE / f"{name}_rays.npz", o=o, d=d, time=tm, origin_prim=frm, hit=hit, prim=prim, t=t, u=u, v=v, second_t=t2,
                             segments=np.array([cnt["segments"]]))
 

@@ -268,6 +268,24 @@ def test_render_matches_committed_golden_images(device):
 
 
 @pytest.mark.parametrize("name", ["c1", "c3"])
+def test_rmse_against_the_committed_converged_image(device, name):
+    """RMSE of a 256-spp device render against the committed 16384-spp oracle frame is no worse
+    than 1.1x the oracle's own RMSE at 256 spp with the same seed (stored beside the frame)."""
+    gold = np.load(GOLD / f"{name}_oracle_64x64_converged.npz")
+    conv = gold["image"].astype(np.float64)
+    fn, kw, mode, _, _ = SCENES[name]
+    host, osb, cam = helpers.build_both(fn, width=64, spp=256)
+    device.upload(host)
+    device.film_resize(64, 64)
+    for seed, want in zip(gold["seeds"].tolist(), gold["rmse_at_256spp"].tolist()):
+        device.film_clear()
+        device.render(cam.build(), mode=mode, seed=seed)
+        gpu = device.film(1.0 / cam.effective_spp).astype(np.float64)
+        rmse = float(np.sqrt(np.mean((gpu - conv) ** 2)))
+        assert 0.5 * want < rmse <= 1.1 * want, (seed, rmse, want)
+
+
+@pytest.mark.parametrize("name", ["c1", "c3"])
 def test_render_statistical_parity_independent_streams(device, name):
     """Per-pixel z-test against oracle renders with an unrelated generator (mt19937_64).  The
     estimators are heavy-tailed (light sampling close to the light, caustic paths), so the

@@ -298,6 +298,21 @@ def test_golden_oracle_images_are_reproduced():
         assert np.array_equal(hit, rays["hit"]) and np.array_equal(prim, rays["prim"]) and np.allclose(t, rays["t"], rtol=1e-13)
 
 
+def test_converged_fixture_is_consistent_with_the_oracle():
+    """The committed 16384-spp frames: an oracle render at 256 spp with one of the recorded seeds
+    lands on the recorded RMSE, and an independent generator lands near it."""
+    for name, fn, mode in (("c1", ra.scenes.cornell_main, orc.MODE_REF_EXACT), ("c3", ra.scenes.cornell_book3, orc.MODE_BOOK3)):
+        gold = np.load(GOLD / f"{name}_oracle_64x64_converged.npz")
+        conv = gold["image"].astype(np.float64)
+        _, osb, cam = helpers.build_both(fn, width=64, spp=256)
+        film, _, _ = orc.render(osb, cam, mode=mode, seed=int(gold["seeds"][0]), threads=8)
+        rmse = np.sqrt(np.mean((film / cam.effective_spp - conv) ** 2))
+        assert rmse == pytest.approx(float(gold["rmse_at_256spp"][0]), rel=1e-4)
+        film, _, _ = orc.render(osb, cam, mode=mode, rng=orc.RNG_MT64, seed=3, threads=8)
+        rmse = np.sqrt(np.mean((film / cam.effective_spp - conv) ** 2))
+        assert 0.6 < rmse / float(np.mean(gold["rmse_at_256spp"])) < 1.5
+
+
 def test_rng_streams_agree_statistically():
     """Philox-24, Philox-53 and mt19937_64 renders have the same mean (independent streams)."""
     _, osb, cam = helpers.build_both(ra.scenes.cornell_main, width=32, spp=64)
