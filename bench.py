@@ -97,9 +97,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-strata", type=int, default=6, help="strata of the full frame the CPU baseline renders")
     ap.add_argument("--wavefront", action="store_true", help="ray-queue pipeline instead of the persistent path kernel")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend (default: nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU machine: every rank uses GPU 0 (needs --backend gloo); the line is marked")
     args = ap.parse_args()
 
-    rank, world, local = rdist.init_from_env()
+    if args.share_gpu:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = rdist.init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -177,6 +182,7 @@ def main():
         "metric": "ray segments/s", "value": round(value, 1), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        **({"rehearsal": "all ranks share GPU 0; not a scaling measurement"} if args.share_gpu else {}),
         "config": {"workload": desc, "name": args.workload, "image": [cam.image_width, cam.image_height],
                    "spp": n_strata, "max_depth": cam.max_depth, "estimator": "book3" if mode == ra.RT_MODE_BOOK3 else "ref-exact",
                    "pipeline": "wavefront" if args.wavefront else "persistent",
