@@ -11,11 +11,14 @@ HOSTFLAGS = -O2 $(CXXSTD) -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contrac
 
 LIB = raytracing_amd/librt_amd.so
 HOST_SRC = raytracing_amd/host/scene.cpp raytracing_amd/host/flatten.cpp raytracing_amd/host/config.cpp \
-           raytracing_amd/host/image_io.cpp raytracing_amd/host/host_capi.cpp
+           raytracing_amd/host/image_io.cpp raytracing_amd/host/host_capi.cpp raytracing_amd/host/render.cpp
 HOST_OBJ = $(HOST_SRC:.cpp=.o)
 DEV_OBJ = raytracing_amd/csrc/rt_device.o
 
-all: $(LIB) oracle
+# the reference's binary (main.rs) on this backend
+MAIN = bin/rt_main
+
+all: $(LIB) $(MAIN) oracle
 
 $(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -26,11 +29,15 @@ raytracing_amd/host/%.o: raytracing_amd/host/%.cpp raytracing_amd/host/raytracin
 $(LIB): $(DEV_OBJ) $(HOST_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(DEV_OBJ) $(HOST_OBJ) -lz
 
+$(MAIN): raytracing_amd/host/main.o $(LIB)
+	mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -o $@ $< -Lraytracing_amd -lrt_amd -Wl,-rpath,'$$ORIGIN/../raytracing_amd'
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB) $(DEV_OBJ) $(HOST_OBJ)
+	rm -f $(LIB) $(DEV_OBJ) $(HOST_OBJ) $(MAIN) raytracing_amd/host/main.o
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

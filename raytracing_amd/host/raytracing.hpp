@@ -314,11 +314,60 @@ class CameraBuilder { // camera.rs:14-202
     std::vector<std::string> errors;
 };
 
+// export.rs:5-8.  write() receives the whole frame, row-major, already scaled by 1/spp.
+class ImageWriter {
+  public:
+    virtual ~ImageWriter() = default;
+    virtual void write_header(uint32_t width, uint32_t height) = 0;
+    virtual void write(const std::vector<Color> &buf) = 0;
+};
+class PpmWriter : public ImageWriter { // export.rs:10-41: P3 text, gamma 2
+  public:
+    explicit PpmWriter(std::string path) : path_(std::move(path)) {}
+    void write_header(uint32_t width, uint32_t height) override { w_ = width, h_ = height; }
+    void write(const std::vector<Color> &buf) override;
+
+  private:
+    std::string path_;
+    uint32_t w_ = 0, h_ = 0;
+};
+class PngWriter : public ImageWriter { // export.rs:43-86: 8-bit RGB, linear values
+  public:
+    explicit PngWriter(std::string path) : path_(std::move(path)) {}
+    void write_header(uint32_t width, uint32_t height) override { w_ = width, h_ = height; }
+    void write(const std::vector<Color> &buf) override;
+
+  private:
+    std::string path_;
+    uint32_t w_ = 0, h_ = 0;
+};
+
+// What the device needs beyond the reference's render(world, lights): which GPU, which
+// estimator (the shipped one by default), and the seed the reference draws from the OS.
+struct RenderSettings {
+    int device_id = 0;
+    uint32_t mode = RT_MODE_REF_EXACT;
+    uint32_t flags = 0; // RT_FLAG_*
+    uint64_t seed = 1;
+};
+struct RenderReport {
+    uint64_t segments = 0, camera_rays = 0, dropped = 0;
+    double render_ms = 0.0;
+};
+
 class Camera {
   public:
     rt_camera derived{};      // everything Camera::build computes (camera.rs:280-366)
     uint32_t samples_per_px;  // sqrt_spp^2
     static Camera build(const rth_camera_builder &b);
+    // Camera::render (camera.rs:368-404) on the device: flattens the scene graph, uploads it,
+    // traces every stratum of every pixel and hands the frame (sums x 1/spp, camera.rs:397) to
+    // the writer.  lights may be null for a scene without sampled lights (RT_MODE_BOOK3 only).
+    // Throws Error with the device's message; there is no CPU rendering path.
+    void render(const Hittable &world, const Hittable *lights, ImageWriter &writer, const RenderSettings &settings = {},
+                RenderReport *report = nullptr) const;
+    std::vector<Color> render(const Hittable &world, const Hittable *lights, const RenderSettings &settings = {},
+                              RenderReport *report = nullptr) const;
 };
 
 // ------------------------------------------------------------------ config (config.rs)

@@ -666,3 +666,46 @@ def test_edge_sizes(device, wavefront):
     assert st.camera_rays == 0 and st.segments == 0 and not device.film().any()
     with pytest.raises(ra.RtError, match="greater than 1"):
         ra.CameraSettings(**{**cam.__dict__, "image_width": 1, "image_height": 1}).build()
+
+
+def test_native_binary_writes_the_same_bytes_as_the_python_route(device, tmp_path):
+    """bin/rt_main is the C++ counterpart of the reference's binary (main.rs:12-72): Camera::render
+    of the C++ host layer over the same C ABI.  Its PNG holds the bytes the device's own 8-bit
+    stage gives for the same scene, size and seed; likewise for a scene file and the PPM rule."""
+    import subprocess
+    from raytracing_amd import imageio, scene_toml
+    root = Path(__file__).resolve().parent.parent
+    exe = root / "bin" / "rt_main"
+    assert exe.exists(), "bin/rt_main is built by make"
+    out = tmp_path / "main.png"
+    r = subprocess.run([str(exe), "--config", str(root / "scenes" / "cornell_box.toml"), "--width", "64", "--spp", "16", "--seed", "3",
+                        "--out", str(out)], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr
+    sb = ra.SceneBuilder()
+    cam = ra.scenes.cornell_main(sb, width=64, spp=16)
+    device.upload(sb)
+    device.film_resize(64, 64)
+    st = device.render(cam.build(), mode=ra.RT_MODE_REF_EXACT, seed=3)
+    want = device.film_rgb8(1.0 / cam.effective_spp)
+    got = imageio.read_png(out)
+    assert got.shape == want.shape and want.max() > 100
+    assert np.array_equal(got, want)
+    assert f"{st.segments} segments" in r.stderr
+    # a scene file, PPM writer (gamma 2)
+    out2 = tmp_path / "book3.ppm"
+    path = root / "scenes" / "cornell_book3" / "cornell_book3.toml"
+    r = subprocess.run([str(exe), "--scene", str(path), "--width", "48", "--spp", "9", "--seed", "5", "--ppm", "--out", str(out2)],
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr
+    sb = ra.SceneBuilder()
+    cam = scene_toml.load_scene_file(sb, path)
+    cam.image_width = cam.image_height = 48
+    cam.samples_per_px = 9
+    device.upload(sb)
+    device.film_resize(48, 48)
+    device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=5)
+    want = device.film_rgb8(1.0 / 9.0, gamma=True)
+    tok = out2.read_text().split()
+    assert tok[:4] == ["P3", "48", "48", "255"]
+    got = np.array(tok[4:], dtype=np.uint8).reshape(48, 48, 3)
+    assert np.array_equal(got, want)

@@ -622,3 +622,21 @@ def test_partition_strata():
         sizes = [e - b for b, e in parts]
         assert max(sizes) - min(sizes) <= 1
     assert partition_strata(961, 8, 0) == (0, 121) and partition_strata(961, 8, 7) == (841, 961)
+
+
+def test_native_binary_fails_loudly_without_a_device_and_reports_builder_errors(tmp_path):
+    """bin/rt_main (main.rs counterpart): no CPU rendering path behind Camera::render, and the
+    CameraBuilder messages of camera.rs:53-55 reach the user."""
+    import subprocess
+    import torch
+    exe = ROOT / "bin" / "rt_main"
+    assert exe.exists(), "bin/rt_main is built by make"
+    r = subprocess.run([str(exe), "--scene", str(ROOT / "scenes" / "book1_final" / "book1_final.toml"), "--width", "1", "--height", "1"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "CameraBuilder::dimensions: Invalid width: must be greater than 1, found 1" in r.stderr
+    r = subprocess.run([str(exe), "--scene", str(tmp_path / "missing.toml")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot read" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([str(exe), "--config", str(ROOT / "scenes" / "cornell_box.toml"), "--out", str(tmp_path / "x.png")],
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "rt_create" in r.stderr and not (tmp_path / "x.png").exists()
