@@ -668,6 +668,40 @@ def test_edge_sizes(device, wavefront):
         ra.CameraSettings(**{**cam.__dict__, "image_width": 1, "image_height": 1}).build()
 
 
+def test_maximum_sizes(device):
+    """Past the limits of the fast index arithmetic (pixel and stratum indices are split by a
+    float reciprocal below 2^24 pixels / 4096 strata per axis, by integer division above): a
+    frame of more than 2^24 pixels and pixels with the largest stratum grid the library takes,
+    4096 x 4096, give the picture the small ones give; a larger grid is refused."""
+    host, osb, cam, mode, _ = scene("c3", device)
+    conv = np.load(GOLD / "c3_oracle_64x64_converged.npz")["image"].astype(np.float64)
+    side = 4104  # 4104^2 = 16.84 M pixels > 2^24
+    assert side * side > 1 << 24 and side % 8 == 0
+    c = ra.CameraSettings(**{**cam.__dict__, "image_width": side, "image_height": side, "samples_per_px": 1})
+    device.film_resize(side, side)
+    st = device.render(c.build(), mode=mode, seed=2)
+    assert st.camera_rays == side * side
+    img = device.film(1.0)
+    assert np.isfinite(img).all()
+    blocks = img.reshape(8, side // 8, 8, side // 8, 3).mean(axis=(1, 3), dtype=np.float64)
+    assert np.allclose(blocks, conv.reshape(8, 8, 8, 8, 3).mean(axis=(1, 3)), rtol=0.05, atol=0.01)
+    del img
+    # 4096^2 strata in each of 2x2 pixels: 67 M samples; the mean agrees with a 64^2-strata render
+    means = []
+    for spp in (4096 * 4096, 64 * 64):
+        c = ra.CameraSettings(**{**cam.__dict__, "image_width": 2, "image_height": 2, "samples_per_px": spp})
+        assert c.effective_spp == spp
+        device.film_resize(2, 2)
+        st = device.render(c.build(), mode=mode, seed=2)
+        assert st.camera_rays == 4 * spp
+        means.append(device.film(1.0 / spp).astype(np.float64))
+    assert np.allclose(means[0], means[1], rtol=0.1, atol=0.02), means
+    c = ra.CameraSettings(**{**cam.__dict__, "image_width": 2, "image_height": 2, "samples_per_px": 4097 * 4097})
+    with pytest.raises(ra.RtError, match="sqrt_spp must be in 1..4096"):
+        device.render(c.build(), mode=mode, seed=2)
+    device.film_resize(64, 64)
+
+
 def test_native_binary_writes_the_same_bytes_as_the_python_route(device, tmp_path):
     """bin/rt_main is the C++ counterpart of the reference's binary (main.rs:12-72): Camera::render
     of the C++ host layer over the same C ABI.  Its PNG holds the bytes the device's own 8-bit
