@@ -178,47 +178,65 @@ __device__ __forceinline__ void two_sum(float a, float b, float &s, float &e) {
 // cancellation: an origin within r/128 of the surface but not on it -- always for objects resting
 // on a ground sphere of radius 1000, rarely otherwise, so most waves skip it.  A ray that starts
 // on the sphere needs neither c nor the low part of centre - o (its root is 2h/a).
-__device__ __forceinline__ bool hit_sphere(float4 s0, float4 s1, V3 o, V3 d, float time, float tlo, float thi,
-                                           bool from_self, float &t) {
-#pragma clang fp contract(off) // the error terms below must see the same roundings as the sums
-    const V3 center = fma3(mk(s1), time, mk(s0));
-    const float r = s0.w, pr = r * r;
-    const float a = len2(d);
-    const float inv_a = 1.0f / a;
-    V3 oc = center - o;
-    float h = dot(d, oc);
-    const float b2 = len2(oc);
-    float c = b2 - pr;
+struct SphereEq { // a t^2 - 2 h t + c = 0 for one ray and one sphere, plain fp32
+    V3 center, oc;
+    float r, pr, a, inv_a, h, b2, disc;
+};
+__device__ __forceinline__ SphereEq sphere_eq(float4 s0, float4 s1, V3 o, V3 d, float time) {
+#pragma clang fp contract(off) // the error terms in sphere_roots must see the same roundings as these sums
+    SphereEq q;
+    q.center = fma3(mk(s1), time, mk(s0));
+    q.r = s0.w, q.pr = q.r * q.r;
+    q.a = len2(d);
+    q.inv_a = 1.0f / q.a;
+    q.oc = q.center - o;
+    q.h = dot(d, q.oc);
+    q.b2 = len2(q.oc);
     // discriminant about the point of closest approach: disc/a = r^2 - |oc - (h/a) d|^2
-    float disc = a * fmaf(r, r, -len2(fma3(d, -(h * inv_a), oc)));
-    if (from_self) {
-        const float root = 2.0f * h * inv_a;
-        if (!(tlo < root && root < thi)) return false;
-        if (disc < 0.0f) return false; // the reference still needs a real discriminant here
-        t = root;
-        return true;
-    }
-    if (fabsf(c) < 0.015625f * fmaxf(b2, pr)) {
+    q.disc = q.a * fmaf(q.r, q.r, -len2(fma3(d, -(q.h * q.inv_a), q.oc)));
+    return q;
+}
+// Both roots, t_near <= t_far; false if the line misses the sphere.
+__device__ __forceinline__ bool sphere_roots(const SphereEq &q, V3 o, V3 d, float &t_near, float &t_far) {
+#pragma clang fp contract(off)
+    V3 oc = q.oc;
+    float h = q.h, disc = q.disc;
+    float c = q.b2 - q.pr;
+    if (fabsf(c) < 0.015625f * fmaxf(q.b2, q.pr)) {
         V3 ol; // oc + ol = centre - o exactly
-        two_sum(center.x, -o.x, oc.x, ol.x);
-        two_sum(center.y, -o.y, oc.y, ol.y);
-        two_sum(center.z, -o.z, oc.z, ol.z);
+        two_sum(q.center.x, -o.x, oc.x, ol.x);
+        two_sum(q.center.y, -o.y, oc.y, ol.y);
+        two_sum(q.center.z, -o.z, oc.z, ol.z);
         h = dot(d, oc) + dot(d, ol);
         // c = |oc|^2 - r^2, compensated
         float px = oc.x * oc.x, py = oc.y * oc.y, pz = oc.z * oc.z;
-        float low = fmaf(oc.x, oc.x, -px) + fmaf(oc.y, oc.y, -py) + fmaf(oc.z, oc.z, -pz) - fmaf(r, r, -pr);
+        float low = fmaf(oc.x, oc.x, -px) + fmaf(oc.y, oc.y, -py) + fmaf(oc.z, oc.z, -pz) - fmaf(q.r, q.r, -q.pr);
         low = fmaf(2.0f, dot(oc, ol), low);
         float s1_, e1, s2_, e2, s3_, e3;
         two_sum(px, py, s1_, e1);
         two_sum(s1_, pz, s2_, e2);
-        two_sum(s2_, -pr, s3_, e3);
+        two_sum(s2_, -q.pr, s3_, e3);
         c = s3_ + (e1 + e2 + e3 + low);
-        disc = fmaf(h, h, -(a * c)); // |c| << r^2 here: this form is the well-conditioned one
+        disc = fmaf(h, h, -(q.a * c)); // |c| << r^2 here: this form is the well-conditioned one
     }
     if (disc < 0.0f) return false;
-    const float q = h + copysignf(sqrtf(disc), h);
-    const float ta = c / q, tb = q * inv_a;
-    const float t_near = fminf(ta, tb), t_far = fmaxf(ta, tb);
+    const float w = h + copysignf(sqrtf(disc), h);
+    const float ta = c / w, tb = w * q.inv_a;
+    t_near = fminf(ta, tb), t_far = fmaxf(ta, tb);
+    return true;
+}
+__device__ __forceinline__ bool hit_sphere(float4 s0, float4 s1, V3 o, V3 d, float time, float tlo, float thi,
+                                           bool from_self, float &t) {
+    const SphereEq q = sphere_eq(s0, s1, o, d, time);
+    if (from_self) {
+        const float root = 2.0f * q.h * q.inv_a;
+        if (!(tlo < root && root < thi)) return false;
+        if (q.disc < 0.0f) return false; // the reference still needs a real discriminant here
+        t = root;
+        return true;
+    }
+    float t_near, t_far;
+    if (!sphere_roots(q, o, d, t_near, t_far)) return false;
     float root = t_near;
     if (!(tlo < root && root < thi)) {
         root = t_far;
@@ -279,8 +297,17 @@ __device__ __forceinline__ bool hit_medium(SceneRef sc, uint32_t idx, V3 o, V3 d
                                            float thi, const RayCtx &rc, float &tout) {
     rt_medium m = sc.media[idx];
     float t1, t2;
-    if (!hit_boundary(sc, m.first, m.count, o, d, time, -RT_INF, RT_INF, t1)) return false;
-    if (!hit_boundary(sc, m.first, m.count, o, d, time, t1 + 0.0001f, RT_INF, t2)) return false;
+    const uint32_t only = sc.refs[m.first];
+    if (m.count == 1 && (only >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE) {
+        // A boundary that is one sphere: Sphere::hit over the universe returns the near root and
+        // over (t1 + 0.0001, inf) the far one (hittable.rs:181-190), so one quadratic gives both.
+        const float4 *S = sc.spheres + 3 * (only & RT_REF_INDEX_MASK);
+        if (!sphere_roots(sphere_eq(S[0], S[1], o, d, time), o, d, t1, t2)) return false;
+        if (!(t1 + 0.0001f < t2)) return false;
+    } else {
+        if (!hit_boundary(sc, m.first, m.count, o, d, time, -RT_INF, RT_INF, t1)) return false;
+        if (!hit_boundary(sc, m.first, m.count, o, d, time, t1 + 0.0001f, RT_INF, t2)) return false;
+    }
     if (t1 < tlo) t1 = tlo;
     if (t2 > thi) t2 = thi;
     if (t1 >= t2) return false;
