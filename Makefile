@@ -18,7 +18,7 @@ DEV_OBJ = raytracing_amd/csrc/rt_device.o
 # the reference's binary (main.rs) on this backend
 MAIN = bin/rt_main
 
-all: $(LIB) $(MAIN) oracle
+all: $(LIB) $(MAIN) oracle sanitize
 
 $(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -33,11 +33,20 @@ $(MAIN): raytracing_amd/host/main.o $(LIB)
 	mkdir -p bin
 	$(HIPCC) --offload-arch=$(ARCH) -o $@ $< -Lraytracing_amd -lrt_amd -Wl,-rpath,'$$ORIGIN/../raytracing_amd'
 
+# the host layer alone (no HIP) under AddressSanitizer + UBSan, with a fuzzing driver
+SAN_SRC = raytracing_amd/host/scene.cpp raytracing_amd/host/flatten.cpp raytracing_amd/host/config.cpp \
+          raytracing_amd/host/image_io.cpp raytracing_amd/host/host_capi.cpp tests/native/host_sanitize.cpp
+sanitize: bin/host_sanitize
+bin/host_sanitize: $(SAN_SRC) raytracing_amd/host/raytracing.hpp raytracing_amd/csrc/rt_accel.h include/rt_amd.h
+	mkdir -p bin
+	g++ -O1 -g $(CXXSTD) -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer \
+	    -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -o $@ $(SAN_SRC) -lz
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB) $(DEV_OBJ) $(HOST_OBJ) $(MAIN) raytracing_amd/host/main.o
+	rm -f $(LIB) $(DEV_OBJ) $(HOST_OBJ) $(MAIN) raytracing_amd/host/main.o bin/host_sanitize
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean sanitize
