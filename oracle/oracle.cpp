@@ -127,7 +127,7 @@ inline void philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], ui
     out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
-enum : uint32_t { STREAM_CAMERA = 0, STREAM_SHADE = 1, STREAM_MEDIUM = 2 };
+enum : uint32_t { STREAM_CAMERA = 0, STREAM_SHADE = 1 };
 
 struct Sampler {
     int kind = ORC_RNG_PHILOX24;
@@ -164,12 +164,23 @@ struct Sampler {
         }
         return f24(next_u32());
     }
-    // one draw per (segment, medium), independent of traversal order
+    // one draw per (segment, medium), independent of traversal order: Philox2x32-10 (Random123),
+    // counter = (pixel, stratum), key = seed, bounce and the medium's primitive id folded into a word
+    static void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t out[2]) {
+        for (int r = 0; r < 10; ++r) {
+            if (r) k += 0x9E3779B9u;
+            const uint64_t p = uint64_t(0xD256D193u) * c0;
+            const uint32_t n0 = uint32_t(p >> 32) ^ k ^ c1;
+            c1 = uint32_t(p);
+            c0 = n0;
+        }
+        out[0] = c0, out[1] = c1;
+    }
     double medium_draw(uint32_t bounce, uint32_t medium_id) {
         if (kind == ORC_RNG_MT64) return next();
-        uint32_t c[4] = {pixel, sample, (bounce << 8) | STREAM_MEDIUM, medium_id};
-        uint32_t o[4];
-        philox4x32_10(c, key, o);
+        const uint32_t k = key[0] + 0x9E3779B9u * (key[1] ^ (bounce * 0x85EBCA6Bu) ^ (medium_id * 0xC2B2AE35u) ^ 0x27D4EB2Fu);
+        uint32_t o[2];
+        philox2x32_10(pixel, sample, k, o);
         return kind == ORC_RNG_PHILOX53 ? f53(o[0], o[1]) : f24(o[0]);
     }
     double range_pm1() { return 2.0 * next() - 1.0; } // Uniform(-1.0..=1.0), vec.rs:213
@@ -1349,6 +1360,7 @@ void orc_tex_value(orc_scene *s, int tex, double u, double v, const double p[3],
     rgb[0] = c.r, rgb[1] = c.g, rgb[2] = c.b;
 }
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { philox4x32_10(ctr, key, out); }
+void orc_philox2x32(const uint32_t ctr[2], uint32_t key, uint32_t out[2]) { Sampler::philox2x32_10(ctr[0], ctr[1], key, out); }
 int orc_aabb_hit(const double bmin[3], const double bmax[3], const double o[3], const double d[3],
                  double tmin, double tmax) {
     BBox b{{bmin[0], bmax[0]}, {bmin[1], bmax[1]}, {bmin[2], bmax[2]}};

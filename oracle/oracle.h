@@ -128,6 +128,7 @@ void orc_interval_expand(double a, double b, double delta, double out[2]);      
 double orc_interval_clamp(double a, double b, double x);        /* :130-138 */
 void orc_tex_value(orc_scene *, int tex, double u, double v, const double p[3], double rgb[3]);
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_philox2x32(const uint32_t ctr[2], uint32_t key, uint32_t out[2]); /* the media's generator */
 int orc_aabb_hit(const double bmin[3], const double bmax[3], const double o[3], const double d[3],
                  double tmin, double tmax);                     /* boundingbox.rs:96-113 */
 int orc_bvh_stats(orc_scene *, int obj, int *nodes, int *depth);

@@ -113,3 +113,9 @@ def philox(ctr, key):
     out = (C.c_uint32 * 4)()
     lib.orc_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
     return list(out)
+
+
+def philox2x32(ctr, key):
+    out = (C.c_uint32 * 2)()
+    lib.orc_philox2x32((C.c_uint32 * 2)(*ctr), C.c_uint32(key), out)
+    return list(out)

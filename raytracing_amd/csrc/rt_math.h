@@ -53,7 +53,7 @@ __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1,
     out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
-enum : uint32_t { STREAM_CAMERA = 0, STREAM_SHADE = 1, STREAM_MEDIUM = 2 };
+enum : uint32_t { STREAM_CAMERA = 0, STREAM_SHADE = 1 };
 
 __device__ __forceinline__ float u24(uint32_t u) { return float(u >> 8) * (1.0f / 16777216.0f); }
 
@@ -86,10 +86,29 @@ struct Rng {
     __device__ __forceinline__ float pm1() { return 2.0f * next() - 1.0f; }
 };
 
+// Philox2x32-10 (Random123): half the multiplies of the four-word generator, for streams that
+// need one number per draw.
+__host__ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key, uint32_t out[2]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) key += 0x9E3779B9u;
+        const uint64_t p = uint64_t(0xD256D193u) * c0;
+        const uint32_t n0 = uint32_t(p >> 32) ^ key ^ c1;
+        c1 = uint32_t(p);
+        c0 = n0;
+    }
+    out[0] = c0, out[1] = c1;
+}
+// Key of a medium's stream: the render seed, the bounce and the medium's primitive id folded into
+// one word (the counter holds pixel and stratum, so two samples never share a counter).
+__host__ __device__ __forceinline__ uint32_t medium_key(uint32_t k0, uint32_t k1, uint32_t bounce, uint32_t medium_id) {
+    return k0 + 0x9E3779B9u * (k1 ^ (bounce * 0x85EBCA6Bu) ^ (medium_id * 0xC2B2AE35u) ^ 0x27D4EB2Fu);
+}
+// One draw per (segment, medium), independent of the order a traversal meets the media in.
 __device__ __forceinline__ float medium_uniform(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample,
                                                 uint32_t bounce, uint32_t medium_id) {
-    uint32_t o[4];
-    philox4x32_10(pixel, sample, (bounce << 8) | STREAM_MEDIUM, medium_id, k0, k1, o);
+    uint32_t o[2];
+    philox2x32_10(pixel, sample, medium_key(k0, k1, bounce, medium_id), o);
     return u24(o[0]);
 }
 

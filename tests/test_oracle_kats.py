@@ -84,6 +84,11 @@ def test_philox_known_answers():
              (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
     for ctr, key, want in kats:
         assert tuple(orc.philox(ctr, key)) == want
+    # Random123 kat_vectors, philox2x32-10 (the generator of the media's free-flight draws)
+    kats2 = [((0, 0), 0, (0xff1dae59, 0x6cd10df2)), ((0xffffffff, 0xffffffff), 0xffffffff, (0x2c3f628b, 0xab4fd7ad)),
+             ((0x243f6a88, 0x85a308d3), 0x13198a2e, (0xdd7ce038, 0xf62a4c12))]
+    for ctr, key, want in kats2:
+        assert tuple(orc.philox2x32(ctr, key)) == want
 
 
 def test_onb_is_orthonormal_and_follows_axis_rule():
