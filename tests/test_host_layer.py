@@ -655,3 +655,18 @@ def test_host_layer_is_clean_under_sanitizers_and_fuzzing(tmp_path):
     r = subprocess.run([str(exe), str(tmp_path)] + [str(f) for f in files], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "host layer: clean" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_bench_refuses_to_run_without_a_device_or_with_a_wrong_world_size():
+    """bench.py measures the HIP path only: without a GPU it stops with a message instead of
+    timing anything else, and --gpus must match the launcher's WORLD_SIZE."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and '"metric"' not in r.stdout
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py")], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "needs a GPU" in r.stderr and '"metric"' not in r.stdout
