@@ -111,8 +111,7 @@ __device__ __forceinline__ float bitsf(uint32_t u) { return __uint_as_float(u); 
 struct Best {
     float t;
     uint32_t ref;
-    float u, v;
-    uint32_t mat; // material id when the scan already had the record in hand, else RT_REF_NONE
+    float u, v; // surface coordinates; the flat scan leaves a quad's for quad_uv (below)
 };
 
 // A 16-byte record element either per lane (vector load) or wave-uniform (scalar load).
@@ -155,6 +154,14 @@ __device__ __forceinline__ bool hit_quad(const float4 *__restrict__ Q, V3 o, V3 
     a = alpha;
     b = beta;
     return true;
+}
+
+// (alpha, beta) of a point of the quad's plane (hittable.rs:355-358): what hit_quad computes on
+// its way, for callers that have only the hit point.
+__device__ __forceinline__ void quad_uv(const float4 *__restrict__ Q, V3 p, float &a, float &b) {
+    const V3 ph = p - mk(Q[0]);
+    a = dot(ph, mk(Q[2]));
+    b = dot(ph, mk(Q[3]));
 }
 
 // Sphere (hittable.rs:166-204).  Roots accepted in (tlo, thi) open (Interval::surrounds).
@@ -342,7 +349,6 @@ __device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, f
         best.ref = r;
         best.u = a;
         best.v = b;
-        best.mat = RT_REF_NONE;
     }
 }
 
@@ -370,7 +376,7 @@ __device__ __forceinline__ void traverse(SceneRef sc, V3 o, V3 d, float time, fl
                                          uint32_t origin_ref, const RayCtx &rc, uint32_t *stack,
                                          const rt_node *lnodes, Best &best) {
     best.t = thi;
-    best.ref = best.mat = RT_REF_NONE;
+    best.ref = RT_REF_NONE;
     best.u = best.v = 0.f;
     V3 inv = {rcp(d.x), rcp(d.y), rcp(d.z)};
     int sp = 0;
@@ -445,7 +451,7 @@ __device__ __forceinline__ void stage_nodes4(SceneRef sc, uint32_t *s_dyn) {
 // cost ~13 % on a scene too deep to leave LDS for nodes).
 __device__ __forceinline__ void trav4_begin(float thi, uint32_t &cur, uint32_t &sp, Best &best) {
     best.t = thi;
-    best.ref = best.mat = RT_REF_NONE;
+    best.ref = RT_REF_NONE;
     best.u = best.v = 0.f;
     sp = 0;
     cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
@@ -564,7 +570,7 @@ __device__ __forceinline__ QuadRec load_quad_rec(const RT_CONST_AS float *p) {
 __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
                                           uint32_t origin_ref, const RayCtx &rc, Best &best) {
     best.t = thi;
-    best.ref = best.mat = RT_REF_NONE;
+    best.ref = RT_REF_NONE;
     best.u = best.v = 0.f;
     const RT_CONST_AS float *Q = as_uniform(sc.flat_quads);
     const uint32_t nq = sc.n_flat_quads;
@@ -589,9 +595,6 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
         const bool ok = inside & (fabsf(denom) >= 1e-8f) & (tt >= tlo) & (tt <= best.t) & (r != origin_ref);
         best.t = ok ? tt : best.t;
         best.ref = ok ? r : best.ref;
-        best.u = ok ? alpha : best.u;
-        best.v = ok ? beta : best.v;
-        best.mat = ok ? fbits(c[7]) : best.mat;
     };
     // Two records in turn, so that no register copies sit between a request and its wait.  The
     // packed array ends with an all-zero record after an odd count (a zero normal never hits)
@@ -601,7 +604,7 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
         // Parallelograms only (the usual case: walls and boxes): two quads per record, their
         // fields interleaved so that every packed instruction takes its scalar operand straight
         // from the loaded register pair, and the accept rule folded into two max3 and a compare
-        // -- 49 vector and ~10 scalar instructions per pair (the general loop below: 64 and ~75;
+        // -- 45 vector and ~10 scalar instructions per pair (the general loop below: ~60 and ~75;
         // the scalar unit issues as slowly as the vector units, so both count).
         //   pair record, 32 floats: qx qy qz nx ny nz ax ay az bx by bz (2 each), ref[2], mat[2], pad
         typedef float v2f __attribute__((ext_vector_type(2)));
@@ -612,9 +615,9 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
             auto f2 = [&](int i) { return v2f{P[2 * i], P[2 * i + 1]}; };
             // the whole record is requested at once, behind one wait (left alone, the compiler
             // fetches refs and materials only where a hit needs them, each behind its own wait)
-            const float ref_bits[2] = {P[24], P[25]}, mat_bits[2] = {P[26], P[27]};
+            const float ref_bits[2] = {P[24], P[25]};
             const v2f first = f2(0), last = f2(11);
-            asm volatile("" ::"s"(ref_bits[0]), "s"(ref_bits[1]), "s"(mat_bits[0]), "s"(mat_bits[1]), "s"(first), "s"(last));
+            asm volatile("" ::"s"(ref_bits[0]), "s"(ref_bits[1]), "s"(first), "s"(last));
             const v2f nx = f2(3), ny = f2(4), nz = f2(5);
             const v2f denom = nx * dx + ny * dy + nz * dz;
             const v2f qox = f2(0) - ox, qoy = f2(1) - oy, qoz = f2(2) - oz;
@@ -634,9 +637,6 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
                 const bool ok = (worst <= 0.0f) & (fabsf(denom[j]) >= 1e-8f) & (r != origin_ref);
                 best.t = ok ? t : best.t;
                 best.ref = ok ? r : best.ref;
-                best.u = ok ? a : best.u;
-                best.v = ok ? b : best.v;
-                best.mat = ok ? fbits(mat_bits[j]) : best.mat;
             }
         }
     } else if (nq) {
@@ -1004,8 +1004,10 @@ struct Surface {
     bool front;
     rt_material m;
 };
+// quad_uv_missing: the hit came from the flat scan, which does not carry a quad's (alpha, beta)
+// through its loop; they are recomputed here for the materials that look at them.
 __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &film, const float4 &ra,
-                                           const float4 &rb, const float4 &sa, float4 h, uint32_t mat_hint,
+                                           const float4 &rb, const float4 &sa, float4 h, bool quad_uv_missing,
                                            Surface &sf) {
     const V3 o = mk(ra), d = mk(rb), thr = mk(sa);
     const float time = ra.w;
@@ -1029,7 +1031,7 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
     if (kind == RT_KIND_QUAD) {
         const float4 *Q = sc.quads + 6 * idx;
         n = mk(Q[1]);
-        mat_id = mat_hint != RT_REF_NONE ? mat_hint : fbits(Q[3].w);
+        mat_id = fbits(Q[3].w);
     } else if (kind == RT_KIND_SPHERE) {
         const float4 *S = sc.spheres + 3 * idx;
         float4 s0 = S[0], s1 = S[1];
@@ -1047,6 +1049,7 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
     }
     const rt_material m = sc.mats[mat_id];
     if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
+    if (kind == RT_KIND_QUAD && quad_uv_missing && m.needs_uv) quad_uv(sc.quads + 6 * idx, p, u, v);
     if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
         // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
         if (front) film_add(film, pixel, thr * (m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p)));
@@ -1155,9 +1158,9 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
 template <int MODE>
 __device__ __forceinline__ bool shade_one(SceneRef sc, CamRef cam, const Film &film, uint32_t k0,
                                           uint32_t k1, float4 &ra, float4 &rb, float4 &sa, uint2 &sb, float4 h,
-                                          uint32_t mat_hint, Ctrl *ctrl) {
+                                          bool quad_uv_missing, Ctrl *ctrl) {
     Surface sf;
-    if (!shade_emit(sc, cam, film, ra, rb, sa, h, mat_hint, sf)) return false;
+    if (!shade_emit(sc, cam, film, ra, rb, sa, h, quad_uv_missing, sf)) return false;
     Rng rng;
     rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
     return shade_scatter<MODE>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
@@ -1174,6 +1177,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, const DScene *scp, con
     const uint32_t n = q.count[chunk];
     if (n == 0) return;
     const size_t cbase = size_t(chunk) * q.cap;
+    const bool flat_world = (sc.n_flat_pairs | sc.n_flat_quads | sc.n_flat_other) != 0; // hits may come from the flat scan
     uint32_t out = 0; // survivors written so far; always <= base, so writes never pass reads
     for (uint32_t base = 0; base < n; base += WAVE) {
         const uint32_t k = base + lane;
@@ -1187,7 +1191,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, const DScene *scp, con
             sa = q.sa[s];
             sb = q.sb[s];
             float4 h = q.hit[s];
-            alive = shade_one<MODE>(sc, cam, film, k0, k1, ra, rb, sa, sb, h, RT_REF_NONE, ctrl);
+            alive = shade_one<MODE>(sc, cam, film, k0, k1, ra, rb, sa, sb, h, flat_world, ctrl);
         }
         // wave-level stream compaction: ballot + mbcnt prefix
         const unsigned long long mask = __ballot(alive);
@@ -1253,7 +1257,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     // heavy-tailed; waiting for the last lane left 12 % of the lanes active on a large scene.
     uint32_t cur = RT_REF_NONE, sp = 0; // cur != RT_REF_NONE: this lane is inside a traversal
     Best best;
-    best.t = RT_INF, best.ref = best.mat = RT_REF_NONE, best.u = best.v = 0.f;
+    best.t = RT_INF, best.ref = RT_REF_NONE, best.u = best.v = 0.f;
     for (;;) {
         bool scatter = false; // the path goes on from a surface
         bool busy = false;    // (wide BVH) this lane is inside a traversal and skips the shading steps
@@ -1277,7 +1281,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
             if (__ballot(alive) == 0 && exhausted) break;
             if (alive && !busy)
                 scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
-                                     RT_REF_NONE, sf);
+                                     false, sf);
         } else {
             // 1. closest hit, then what the hit itself contributes (background, emission)
             const unsigned long long live = __ballot(alive);
@@ -1287,7 +1291,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                 RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
                 closest_hit<ACCEL, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack, s_nodes, s_dyn, best);
                 scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
-                                     best.mat, sf);
+                                     ACCEL == ACCEL_FLAT, sf);
             }
         }
         // 2. idle lanes take new samples
@@ -1379,6 +1383,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(const DScene *scp, ui
         uint32_t kind = best.ref >> RT_REF_KIND_SHIFT, idx = best.ref & RT_REF_INDEX_MASK;
         if (kind == RT_KIND_QUAD) {
             pid = int(fbits(sc.quads[6 * idx + 4].w));
+            if (ACCEL == ACCEL_FLAT) quad_uv(sc.quads + 6 * idx, fma3(d, best.t, o), uu, vv);
         } else if (kind == RT_KIND_SPHERE) {
             const float4 *S = sc.spheres + 3 * idx;
             float4 s0 = S[0], s1 = S[1], s2 = S[2];

@@ -478,6 +478,42 @@ def test_textures_on_device_match_oracle(device):
             assert bad.mean() < 2e-3, (name, bad.sum())
 
 
+@pytest.mark.parametrize("wavefront", [False, True], ids=["persistent", "wavefront"])
+def test_image_textured_quads_in_a_flat_world(device, wavefront):
+    """The flat scan does not carry a quad's (alpha, beta) through its loop; a material that looks
+    at them (an image texture, also nested in a checker and on an emitter) gets them recomputed
+    from the hit point.  Same-stream render of a one-list world against the oracle, and the
+    intersection hook's u, v."""
+    rng = np.random.default_rng(11)
+    img = (rng.random((8, 8, 3)) * 255).astype(np.uint8)
+    host, osb = ra.SceneBuilder(), orc.scene()
+    for sb in (host, osb):
+        im = sb.tex_image(img)
+        chk = sb.tex_checker(0.8, im, sb.tex_solid(0.7, 0.7, 0.2))
+        wall = sb.quad((-2, -2, -3), (4, 0, 0), (0, 4, 0), sb.lambertian(im))
+        floor = sb.quad((-2, -2, -3), (4, 0, 0), (0, 0, 4), sb.lambertian(chk))
+        tri = sb.quad((-2, -2, -3), (0, 4, 0), (0, 0, 4), sb.lambertian(sb.tex_solid(0.6, 0.6, 0.6)), shape=1)
+        lamp = sb.quad((-1, 1.9, -2), (2, 0, 0), (0, 0, 1), sb.light(im))
+        sb.set_world(sb.list([wall, floor, tri, lamp]))
+        sb.set_lights(lamp)
+    cam = ra.CameraSettings(image_width=48, image_height=48, samples_per_px=16, max_depth=6, vfov=70.0, background=(0.0, 0.0, 0.0),
+                            camera_center=(0.3, 0.2, 2.5), camera_target=(0.0, -0.3, -3.0))
+    device.upload(host)
+    assert device.accel_info()["kind"] == "flat"
+    device.film_resize(48, 48)
+    device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=3, wavefront=wavefront)
+    gpu = device.film(1.0 / 16)
+    film, _, _ = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=3)
+    r = helpers.compare_same_stream(gpu, film / 16)
+    assert gpu.max() > 0.1 and r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.05, r
+    o = np.tile(np.array([[0.3, 0.2, 2.5]], np.float32), (2000, 1))
+    d = np.concatenate([rng.random((2000, 2)) * 4 - 2, np.full((2000, 1), -5.5)], axis=1).astype(np.float32)
+    hit, prim, t, u, v = device.intersect_batch(o, d, np.zeros(2000, np.float32))
+    h2, p2, t2, u2, v2, _ = orc.intersect_batch(osb, o, d, np.zeros(2000))
+    same = (hit == 1) & (h2 == 1) & (prim == p2)
+    assert same.mean() > 0.5 and np.abs(u[same] - u2[same]).max() < 1e-4 and np.abs(v[same] - v2[same]).max() < 1e-4
+
+
 def test_ref_exact_rejects_what_the_reference_cannot_render(device):
     host, osb, cam, mode, _ = scene("c3", device)  # glass sphere, light list
     with pytest.raises(ra.RtError, match="todo"):
