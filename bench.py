@@ -57,8 +57,8 @@ FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path dep
 FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0}
 # HBM-side bytes per segment of the persistent kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
 # WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments;
-# profiles/r1f_pmc_c3_spp64_persistent.txt).  Not collected live: counters need their own runs.
-PMC_BYTES_PER_SEGMENT = {"c3": (2 * 14446 + 4909440) * 1024 / 861.4e6}
+# profiles/r1g_pmc_c3_spp64_persistent.txt).  Not collected live: counters need their own runs.
+PMC_BYTES_PER_SEGMENT = {"c3": (2 * 12796 + 4905618) * 1024 / 861.4e6}
 
 
 def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads):
