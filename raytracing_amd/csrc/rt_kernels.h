@@ -1218,6 +1218,12 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, const DScene *scp, con
 // keyed by (pixel, stratum, bounce), the image does not depend on which lane traces what.
 // Exit: a wave leaves when the counter has passed total_samples and its lanes are idle; both
 // are reached by every wave since a path ends after at most max_depth bounces.
+// Smallest range a wave asks the counter for on a flat world.  All waves add to one address, which
+// takes ~90 M atomics/s; there a wave uses up 2-5 samples per microsecond, so with 4096 waves
+// asking, ranges below ~250 samples make the counter the bottleneck (a 0.7 ms frame took 0.25 ms
+// longer with 64).  Behind a BVH a sample costs 10-100 times more and the smallest range stays
+// one wave's worth, for the balance at the end of the frame.
+constexpr uint32_t MIN_TAKE_FLAT = 256;
 __device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
     uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(x));
     uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(x >> 32));
@@ -1304,7 +1310,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                 // from the counter value this wave saw last), so the last waves finish together
                 const float left = float(total > seen ? total - seen : 0ull);
                 uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
-                take = take < uint32_t(WAVE) ? uint32_t(WAVE) : (take & ~uint32_t(WAVE - 1));
+                const uint32_t min_take = ACCEL == ACCEL_FLAT ? MIN_TAKE_FLAT : uint32_t(WAVE);
+                take = take < min_take ? min_take : (take & ~uint32_t(WAVE - 1));
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(take));
                 b = wave_first(b);
