@@ -1013,50 +1013,55 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
     const float time = ra.w;
     const uint32_t pixel = fbits(sa.w);
     const uint32_t ref = fbits(h.y);
+    // one deposit site for the two ways a path ends here (background, emission)
+    V3 deposit = {0.f, 0.f, 0.f};
+    bool surface = false;
     if (ref == RT_REF_NONE) { // camera.rs:445-448, 473-482
         V3 bg = ldv(cam.bg);
         if (cam.sky) {
             float a = 0.5f * (unit(d).y + 1.0f);
             bg = (1.0f - a) * V3{1.f, 1.f, 1.f} + a * V3{0.5f, 0.7f, 1.0f};
         }
-        film_add(film, pixel, thr * bg);
-        return false;
+        deposit = bg;
+    } else {
+        const V3 p = fma3(d, h.x, o);
+        const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+        V3 n;
+        uint32_t mat_id;
+        float u = h.z, v = h.w, u_shift = 0.f;
+        bool front = true;
+        if (kind == RT_KIND_QUAD) {
+            const float4 *Q = sc.quads + 6 * idx;
+            n = mk(Q[1]);
+            mat_id = fbits(Q[3].w);
+        } else if (kind == RT_KIND_SPHERE) {
+            const float4 *S = sc.spheres + 3 * idx;
+            float4 s0 = S[0], s1 = S[1];
+            V3 center = fma3(mk(s1), time, mk(s0));
+            n = (p - center) * rcp(s0.w);
+            mat_id = fbits(s1.w);
+            u_shift = S[2].z;
+        } else { // ConstantMedium: arbitrary normal, front face (hittable.rs:877-885)
+            n = {1.f, 0.f, 0.f};
+            mat_id = sc.media[idx].mat;
+        }
+        if (kind != RT_KIND_MEDIUM) { // HitRecord::from_incoming_ray (hittable.rs:59-79)
+            front = dot(d, n) < 0.0f;
+            if (!front) n = -n;
+        }
+        const rt_material m = sc.mats[mat_id];
+        if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
+        if (kind == RT_KIND_QUAD && quad_uv_missing && m.needs_uv) quad_uv(sc.quads + 6 * idx, p, u, v);
+        if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
+            // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
+            if (front) deposit = m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p);
+        } else {
+            sf.p = p, sf.n = n, sf.u = u, sf.v = v, sf.ref = ref, sf.front = front, sf.m = m;
+            surface = true;
+        }
     }
-    const V3 p = fma3(d, h.x, o);
-    const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
-    V3 n;
-    uint32_t mat_id;
-    float u = h.z, v = h.w, u_shift = 0.f;
-    bool front = true;
-    if (kind == RT_KIND_QUAD) {
-        const float4 *Q = sc.quads + 6 * idx;
-        n = mk(Q[1]);
-        mat_id = fbits(Q[3].w);
-    } else if (kind == RT_KIND_SPHERE) {
-        const float4 *S = sc.spheres + 3 * idx;
-        float4 s0 = S[0], s1 = S[1];
-        V3 center = fma3(mk(s1), time, mk(s0));
-        n = (p - center) * rcp(s0.w);
-        mat_id = fbits(s1.w);
-        u_shift = S[2].z;
-    } else { // ConstantMedium: arbitrary normal, front face (hittable.rs:877-885)
-        n = {1.f, 0.f, 0.f};
-        mat_id = sc.media[idx].mat;
-    }
-    if (kind != RT_KIND_MEDIUM) { // HitRecord::from_incoming_ray (hittable.rs:59-79)
-        front = dot(d, n) < 0.0f;
-        if (!front) n = -n;
-    }
-    const rt_material m = sc.mats[mat_id];
-    if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
-    if (kind == RT_KIND_QUAD && quad_uv_missing && m.needs_uv) quad_uv(sc.quads + 6 * idx, p, u, v);
-    if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
-        // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
-        if (front) film_add(film, pixel, thr * (m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p)));
-        return false;
-    }
-    sf.p = p, sf.n = n, sf.u = u, sf.v = v, sf.ref = ref, sf.front = front, sf.m = m;
-    return true;
+    if (!surface) film_add(film, pixel, thr * deposit);
+    return surface;
 }
 
 // camera.rs:455-470: scatter at a surface, choose the next direction, weigh it.  rng is the
