@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-strata", type=int, default=6, help="strata of the full frame the CPU baseline renders")
     ap.add_argument("--wavefront", action="store_true", help="ray-queue pipeline instead of the persistent path kernel")
+    ap.add_argument("--regroup", action="store_true", help="persistent kernel with per-wave regrouping of paths (flat worlds)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU machine: every rank uses GPU 0 (needs --backend gloo); the line is marked")
@@ -130,6 +131,8 @@ def main():
         torch.cuda.synchronize()
 
     extra = dict(wavefront=True, pool_size=args.pool, time_every=8) if args.wavefront else {}
+    if args.regroup:
+        extra["regroup"] = True
     for _ in range(args.warmup):
         renderer.render(rcam, n_strata, rank, world, mode, seed=1, **extra)
     barrier()

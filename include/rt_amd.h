@@ -167,6 +167,8 @@ typedef struct {
 #define RT_FLAG_TIME_KERNELS 1u /* bracket kernels with HIP events (see rt_stats) */
 #define RT_FLAG_WAVEFRONT 2u    /* ray-queue pipeline (scan/generate/extend/shade launches) instead of
                                  * the persistent path kernel; same image for the same seed */
+#define RT_FLAG_REGROUP 4u      /* persistent kernel, flat worlds: paths regrouped by the step they wait for
+                                 * (per-wave pools in LDS) instead of one path per lane; same image */
 typedef struct {
     uint32_t mode;
     uint32_t flags;

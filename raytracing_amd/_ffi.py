@@ -90,6 +90,7 @@ class RtAccelInfo(C.Structure):
 RT_BUILD_REFERENCE, RT_BUILD_SAH, RT_BUILD_AUTO = 0, 1, 2
 RT_FLAG_TIME_KERNELS = 1
 RT_FLAG_WAVEFRONT = 2
+RT_FLAG_REGROUP = 4
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
 RT_NODE_LEAF = 0xFFFFFFFF
 

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _ffi
-from ._ffi import (CameraBuilderStruct, RtCamera, RtRenderParams, RtSceneDesc, RtStats, RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT,
+from ._ffi import (CameraBuilderStruct, RtCamera, RtRenderParams, RtSceneDesc, RtStats, RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT, RT_FLAG_REGROUP,
                    RT_MODE_BOOK3, RT_MODE_REF_EXACT)
 
 SHAPE_PARALLELOGRAM, SHAPE_TRIANGLE, SHAPE_DISC = 0, 1, 2
@@ -303,12 +303,13 @@ class Device:
         self._check(self.lib.rt_film_clear(self.h), "rt_film_clear")
 
     def render(self, cam: RtCamera, mode=RT_MODE_REF_EXACT, seed=1, stratum_begin=0, stratum_end=0, pool_size=0,
-               time_kernels=False, time_every=0, wavefront=False, refill_min=0, waves_per_simd=0):
+               time_kernels=False, time_every=0, wavefront=False, refill_min=0, waves_per_simd=0, regroup=False):
         """Adds strata [begin, end) of every pixel into the film (camera.rs:386-401).
         wavefront=True takes the ray-queue pipeline instead of the persistent path kernel."""
         p = RtRenderParams()
         p.mode, p.seed = mode, seed
-        p.flags = (RT_FLAG_TIME_KERNELS if time_kernels else 0) | (RT_FLAG_WAVEFRONT if wavefront else 0)
+        p.flags = (RT_FLAG_TIME_KERNELS if time_kernels else 0) | (RT_FLAG_WAVEFRONT if wavefront else 0) | \
+            (RT_FLAG_REGROUP if regroup else 0)
         p.refill_min, p.waves_per_simd = refill_min, waves_per_simd
         p.stratum_begin, p.stratum_end, p.pool_size, p.time_every = stratum_begin, stratum_end, pool_size, time_every
         self._check(self.lib.rt_render(self.h, C.byref(cam), C.byref(p)), "rt_render")

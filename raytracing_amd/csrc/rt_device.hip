@@ -344,16 +344,44 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
     return 0;
 }
 
+// The regrouping variant of the persistent kernel (flat worlds): same launch shape.
+template <int MODE>
+int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &film, unsigned long long total) {
+    auto kernel = k_paths_regroup<MODE>;
+    int per_cu = 0, n_cu = 0;
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
+    RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
+    if (p->waves_per_simd && int(p->waves_per_simd) < per_cu) per_cu = int(p->waves_per_simd);
+    const unsigned long long per_block = (unsigned long long)REGROUP_SLOTS * (BLOCK / WAVE);
+    unsigned long long blocks_needed = (total + per_block - 1) / per_block;
+    unsigned long long blocks = (unsigned long long)per_cu * n_cu;
+    if (blocks > blocks_needed) blocks = blocks_needed;
+    Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
+    int e = tm.begin(4);
+    kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), 0, h->stream>>>(h->d_sc, h->d_cam, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
+                                                                 h->d_ctrl, h->has_media, 1024u);
+    tm.end(e);
+    RT_HIP(hipGetLastError());
+    h->stats.launches[4]++;
+    return 0;
+}
+
 int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
                       unsigned long long total) {
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
     int rc;
+    if (h->accel == ACCEL_FLAT && (p->flags & RT_FLAG_REGROUP)) {
+        rc = p->mode == RT_MODE_REF_EXACT ? launch_paths_regroup<RT_MODE_REF_EXACT>(h, p, film, total)
+                                          : launch_paths_regroup<RT_MODE_BOOK3>(h, p, film, total);
+    } else {
 #define RT_PATHS(MODE)                                                                                    \
     (h->accel == ACCEL_FLAT   ? launch_paths<MODE, ACCEL_FLAT>(h, dc, p, film, total)                        \
      : h->accel == ACCEL_BVH4 ? launch_paths<MODE, ACCEL_BVH4>(h, dc, p, film, total)                        \
                               : launch_paths<MODE, ACCEL_BVH2>(h, dc, p, film, total))
     rc = p->mode == RT_MODE_REF_EXACT ? RT_PATHS(RT_MODE_REF_EXACT) : RT_PATHS(RT_MODE_BOOK3);
 #undef RT_PATHS
+    }
     if (rc) return rc;
     RT_HIP(hipEventRecord(h->ev_end, h->stream));
     RT_HIP(hipMemcpyAsync(&h->h_ctrl[0], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
@@ -372,6 +400,15 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
 } // namespace
 
 extern "C" {
+
+#ifdef RT_REGROUP_STATS
+// instrumented builds only: turns and lanes per step of k_paths_regroup since the last call
+int rt_debug_regroup_stats(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rg_stats), sizeof(unsigned long long) * 2 * RG_LISTS) != hipSuccess) return -1;
+    unsigned long long zero[2 * RG_LISTS] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int rt_device_count(int *n) {
     rt_handle *h = nullptr;

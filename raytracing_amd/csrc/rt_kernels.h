@@ -20,6 +20,7 @@
 //              film accumulation (camera.rs:451-470), compaction of surviving rays.
 #pragma once
 #include "rt_math.h"
+#include <type_traits>
 #include "../../include/rt_amd.h"
 
 namespace rt {
@@ -1006,6 +1007,9 @@ struct Surface {
 };
 // quad_uv_missing: the hit came from the flat scan, which does not carry a quad's (alpha, beta)
 // through its loop; they are recomputed here for the materials that look at them.
+// DEPOSIT = false: the caller knows the hit is a surface that scatters (k_paths_regroup's scatter
+// steps); only `sf` is wanted.
+template <bool DEPOSIT = true>
 __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &film, const float4 &ra,
                                            const float4 &rb, const float4 &sa, float4 h, bool quad_uv_missing,
                                            Surface &sf) {
@@ -1016,7 +1020,7 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
     // one deposit site for the two ways a path ends here (background, emission)
     V3 deposit = {0.f, 0.f, 0.f};
     bool surface = false;
-    if (ref == RT_REF_NONE) { // camera.rs:445-448, 473-482
+    if (DEPOSIT && ref == RT_REF_NONE) { // camera.rs:445-448, 473-482
         V3 bg = ldv(cam.bg);
         if (cam.sky) {
             float a = 0.5f * (unit(d).y + 1.0f);
@@ -1052,7 +1056,7 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
         const rt_material m = sc.mats[mat_id];
         if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
         if (kind == RT_KIND_QUAD && quad_uv_missing && m.needs_uv) quad_uv(sc.quads + 6 * idx, p, u, v);
-        if (m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
+        if (DEPOSIT && m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
             // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
             if (front) deposit = m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p);
         } else {
@@ -1060,13 +1064,17 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
             surface = true;
         }
     }
-    if (!surface) film_add(film, pixel, thr * deposit);
+    if (DEPOSIT && !surface) film_add(film, pixel, thr * deposit);
     return surface;
 }
 
 // camera.rs:455-470: scatter at a surface, choose the next direction, weigh it.  rng is the
 // vertex's shading stream, begun by the caller.  Returns true if the path continues.
-template <int MODE>
+// ONLY: the caller has sorted vertices by material and this call sees one kind -- RT_MAT_METAL,
+// RT_MAT_DIELECTRIC, or RT_MAT_LAMBERTIAN for the two materials that scatter through a PDF; the
+// other branches are compiled out.  SCATTER_ANY: every material, chosen per lane.
+constexpr uint32_t SCATTER_ANY = 0xFFu;
+template <int MODE, uint32_t ONLY = SCATTER_ANY>
 __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &ra, float4 &rb, float4 &sa,
                                               uint2 &sb, const Surface &sf, Rng &rng, Ctrl *ctrl) {
     const V3 d = mk(rb), p = sf.p, n = sf.n;
@@ -1076,13 +1084,13 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
     V3 dir, att;
     float weight = 1.0f;
 
-    if (m.type == RT_MAT_METAL) { // material.rs:115-131 (specular: attenuation * L(reflected))
+    if (ONLY == SCATTER_ANY ? m.type == RT_MAT_METAL : ONLY == RT_MAT_METAL) { // material.rs:115-131 (specular: attenuation * L(reflected))
         V3 refl = d - n * (2.0f * dot(d, n));
         dir = unit(refl);
         if (m.param > 0.f) dir = dir + m.param * random_in_unit_sphere(rng);
         if (dot(dir, n) < 0.0f) return false;
         att = {m.albedo[0], m.albedo[1], m.albedo[2]};
-    } else if (m.type == RT_MAT_DIELECTRIC) { // material.rs:154-182, vec.rs:289-295
+    } else if (ONLY == SCATTER_ANY ? m.type == RT_MAT_DIELECTRIC : ONLY == RT_MAT_DIELECTRIC) { // material.rs:154-182, vec.rs:289-295
         float ri = sf.front ? rcp(m.param) : m.param;
         V3 ud = unit(d);
         float cos_theta = fminf(-dot(ud, n), 1.0f);
@@ -1369,6 +1377,206 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     if (lane == 0) {
         atomicAdd(&ctrl->segments, n_seg);
         atomicAdd(&ctrl->camera_rays, n_cam);
+    }
+}
+
+// ------------------------------------------------------------------ persistent path kernel, regrouping
+// Flat worlds.  The same loop as k_paths, but a path is not tied to a lane: every wave keeps a pool
+// of REGROUP_SLOTS paths in LDS and, per pool, one list of slot numbers for every kind of work a
+// path can be waiting for -- a camera ray to make (free slot), a closest hit to find, a scatter at
+// a diffuse / metal / glass vertex.  Each turn the wave takes up to 64 slots from the fullest
+// list and runs that one step for them, so the step's code runs with most lanes active instead of
+// the 10-20 of 64 that want it in a wave of lane-bound paths.  The pool belongs to one wave:
+// lists are pushed with ballot + mbcnt prefixes, there are no barriers and no atomics.  Every
+// random number is keyed by (pixel, stratum, bounce), so the image equals k_paths'.
+// Exit: a wave leaves when the sample counter has run out and every list but the free one is
+// empty; each step moves its slots on and a path ends within max_depth bounces.
+#ifndef RT_REGROUP_SLOTS
+#define RT_REGROUP_SLOTS 128
+#endif
+constexpr int REGROUP_SLOTS = RT_REGROUP_SLOTS;
+enum : uint32_t { RG_FREE = 0, RG_RAY = 1, RG_DIFFUSE = 2, RG_METAL = 3, RG_GLASS = 4, RG_LISTS = 5 };
+struct RegroupPool {
+    float4 ra[REGROUP_SLOTS], rb[REGROUP_SLOTS], sa[REGROUP_SLOTS]; // as in k_paths
+    uint4 sh[REGROUP_SLOTS];                                        // stratum, bounce, t and ref of the hit to scatter at
+    uint8_t list[RG_LISTS][REGROUP_SLOTS];
+};
+static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE, "slot numbers are bytes");
+#ifndef RT_REGROUP_WAVES
+#define RT_REGROUP_WAVES 4
+#endif
+#ifdef RT_REGROUP_STATS
+__device__ unsigned long long g_rg_stats[2 * RG_LISTS]; // turns and lanes per step (instrumented builds)
+#define RT_RG_COUNT(stage, m) (rg_turns[stage] += 1, rg_lanes[stage] += (m))
+#else
+#define RT_RG_COUNT(stage, m) ((void)0)
+#endif
+
+template <int MODE>
+__global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const DScene *scp, const DCamera *camp, Film film, uint32_t k0,
+                                                          uint32_t k1, Ctrl *ctrl, uint32_t has_media, uint32_t grab) {
+    SceneRef sc = *as_uniform(scp);
+    CamRef cam = *as_uniform(camp);
+    __shared__ RegroupPool s_pool[BLOCK / WAVE];
+    RegroupPool &pool = s_pool[threadIdx.x / WAVE];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    for (uint32_t i = lane; i < uint32_t(REGROUP_SLOTS); i += WAVE) pool.list[RG_FREE][i] = uint8_t(i);
+    // list lengths, wave-uniform
+    uint32_t n_free = REGROUP_SLOTS, n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0;
+    const unsigned long long total = ctrl->total_samples;
+    unsigned long long next = 0, end = 0, seen = 0; // sample ids this wave owns; counter value at its last request
+    const float inv_share = 1.0f / (4.0f * float(gridDim.x * (BLOCK / WAVE)));
+    uint32_t next_pixel = 0, next_stratum = 0;
+    unsigned long long n_seg = 0, n_cam = 0;
+    bool exhausted = false;
+#ifdef RT_REGROUP_STATS
+    unsigned long long rg_turns[RG_LISTS] = {}, rg_lanes[RG_LISTS] = {};
+#endif
+    // appends the slots of the lanes where `yes` holds to list `which`
+    auto push = [&](uint32_t which, uint32_t &n, bool yes, uint32_t slot) {
+        const unsigned long long mask = __ballot(yes);
+        if (mask == 0) return; // uniform
+        const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+        if (yes) pool.list[which][n + prefix] = uint8_t(slot);
+        n += uint32_t(__popcll(mask));
+    };
+    for (;;) {
+        // lanes of one wave run in step, so LDS written in one turn is read back in the next
+        // without a barrier; the fence keeps the compiler from moving accesses across turns
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the fullest list, 64 counting as full; ties go to the step later in a path's turn
+        uint32_t stage = RG_RAY, most = min(n_ray, uint32_t(WAVE));
+        auto offer = [&](uint32_t which, uint32_t n) {
+            const uint32_t c = min(n, uint32_t(WAVE));
+            if (c > most) most = c, stage = which;
+        };
+        offer(RG_DIFFUSE, n_diffuse);
+        offer(RG_GLASS, n_glass);
+        offer(RG_METAL, n_metal);
+        if (!exhausted) offer(RG_FREE, n_free);
+        if (most == 0) break;
+
+        if (stage == RG_FREE) {
+            // camera rays for free slots (camera.rs:409-430)
+            if (next == end) {
+                const float left = float(total > seen ? total - seen : 0ull);
+                uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
+                take = take < MIN_TAKE_FLAT ? MIN_TAKE_FLAT : (take & ~uint32_t(WAVE - 1));
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(take));
+                b = wave_first(b);
+                seen = b;
+                next = b < total ? b : total;
+                end = b + take < total ? b + take : total;
+                exhausted = next == end;
+                next_pixel = uint32_t(next % cam.npix);
+                next_stratum = cam.stratum_begin + uint32_t(next / cam.npix);
+            }
+            const uint32_t m = uint32_t(end - next < most ? end - next : most);
+            if (m == 0) continue;
+            RT_RG_COUNT(RG_FREE, m);
+            n_free -= m;
+            if (lane < m) {
+                const uint32_t slot = pool.list[RG_FREE][n_free + lane];
+                uint32_t px = next_pixel + lane, st = next_stratum;
+                while (px >= cam.npix) px -= cam.npix, ++st;
+                Rng rng;
+                rng.begin(k0, k1, px, st, STREAM_CAMERA, 0);
+                V3 o, d;
+                float time;
+                camera_ray(cam, px, st, rng, o, d, time);
+                pool.ra[slot] = make_float4(o.x, o.y, o.z, time);
+                pool.rb[slot] = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
+                pool.sa[slot] = make_float4(1.f, 1.f, 1.f, bitsf(px));
+                pool.sh[slot] = make_uint4(st, 0u, 0u, RT_REF_NONE);
+                pool.list[RG_RAY][n_ray + lane] = uint8_t(slot);
+            }
+            n_ray += m;
+            next += m;
+            n_cam += m;
+            next_pixel += m;
+            while (next_pixel >= cam.npix) next_pixel -= cam.npix, ++next_stratum;
+        } else if (stage == RG_RAY) {
+            // closest hit, and what the hit itself contributes (camera.rs:444-453)
+            const uint32_t m = most;
+            RT_RG_COUNT(RG_RAY, m);
+            n_ray -= m;
+            n_seg += m;
+            const bool active = lane < m;
+            uint32_t slot = 0, kind = RG_LISTS;
+            if (active) {
+                slot = pool.list[RG_RAY][n_ray + lane];
+                const float4 ra = pool.ra[slot], rb = pool.rb[slot];
+                RayCtx rc{k0, k1, 0u, 0u, 0u};
+                if (has_media) { // a medium keys its free-flight draw by the sample and the bounce
+                    const uint4 sh = pool.sh[slot];
+                    rc.pixel = fbits(pool.sa[slot].w), rc.sample = sh.x, rc.bounce = sh.y;
+                }
+                Best best;
+                scan_flat(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
+                // the material's kind decides where the path waits next; a miss ends it like a light
+                uint32_t type = RT_MAT_LIGHT;
+                if (best.ref != RT_REF_NONE) {
+                    const uint32_t pk = best.ref >> RT_REF_KIND_SHIFT, idx = best.ref & RT_REF_INDEX_MASK;
+                    const uint32_t mat_id = pk == RT_KIND_QUAD     ? fbits(sc.quads[6 * idx + 3].w)
+                                            : pk == RT_KIND_SPHERE ? fbits(sc.spheres[3 * idx + 1].w)
+                                                                   : sc.media[idx].mat;
+                    type = sc.mats[mat_id].type;
+                }
+                if (type == RT_MAT_LIGHT) {
+                    Surface sf;
+                    (void)shade_emit(sc, cam, film, ra, rb, pool.sa[slot], make_float4(best.t, bitsf(best.ref), 0.f, 0.f), true, sf);
+                    kind = RG_FREE;
+                } else {
+                    reinterpret_cast<uint2 *>(&pool.sh[slot])[1] = make_uint2(fbits(best.t), best.ref);
+                    kind = type == RT_MAT_METAL ? RG_METAL : (type == RT_MAT_DIELECTRIC ? RG_GLASS : RG_DIFFUSE);
+                }
+            }
+            push(RG_DIFFUSE, n_diffuse, kind == RG_DIFFUSE, slot);
+            push(RG_FREE, n_free, kind == RG_FREE, slot);
+            push(RG_GLASS, n_glass, kind == RG_GLASS, slot);
+            push(RG_METAL, n_metal, kind == RG_METAL, slot);
+        } else {
+            // scatter at the vertices of one kind (camera.rs:455-470)
+            const uint32_t m = most;
+            auto scatter_turn = [&](auto only, uint32_t &n_list) {
+                constexpr uint32_t ONLY = decltype(only)::value;
+                RT_RG_COUNT(stage, m);
+                n_list -= m;
+                const bool active = lane < m;
+                uint32_t slot = 0;
+                bool alive = false;
+                if (active) {
+                    slot = pool.list[stage][n_list + lane];
+                    float4 ra = pool.ra[slot], rb = pool.rb[slot], sa = pool.sa[slot];
+                    const uint4 sh = pool.sh[slot];
+                    uint2 sb = make_uint2(sh.x, sh.y);
+                    Surface sf;
+                    (void)shade_emit<false>(sc, cam, film, ra, rb, sa, make_float4(bitsf(sh.z), bitsf(sh.w), 0.f, 0.f), true, sf);
+                    Rng rng;
+                    rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
+                    alive = shade_scatter<MODE, ONLY>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+                    if (alive) {
+                        pool.ra[slot] = ra;
+                        pool.rb[slot] = rb;
+                        pool.sa[slot] = sa;
+                        reinterpret_cast<uint2 *>(&pool.sh[slot])[0] = sb;
+                    }
+                }
+                push(RG_RAY, n_ray, alive, slot);
+                push(RG_FREE, n_free, active && !alive, slot);
+            };
+            if (stage == RG_DIFFUSE) scatter_turn(std::integral_constant<uint32_t, RT_MAT_LAMBERTIAN>{}, n_diffuse);
+            else if (stage == RG_GLASS) scatter_turn(std::integral_constant<uint32_t, RT_MAT_DIELECTRIC>{}, n_glass);
+            else scatter_turn(std::integral_constant<uint32_t, RT_MAT_METAL>{}, n_metal);
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&ctrl->segments, n_seg);
+        atomicAdd(&ctrl->camera_rays, n_cam);
+#ifdef RT_REGROUP_STATS
+        for (uint32_t i = 0; i < RG_LISTS; ++i) atomicAdd(&g_rg_stats[i], rg_turns[i]), atomicAdd(&g_rg_stats[RG_LISTS + i], rg_lanes[i]);
+#endif
     }
 }
 
