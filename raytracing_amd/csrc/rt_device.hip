@@ -371,7 +371,9 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
                       unsigned long long total) {
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
     int rc;
-    if (h->accel == ACCEL_FLAT && (p->flags & RT_FLAG_REGROUP)) {
+    // the regrouping kernel packs stratum and bounce into one word
+    const bool regroup_fits = dc.sqrt_spp <= 4096u && dc.max_depth <= REGROUP_MAX_DEPTH;
+    if (h->accel == ACCEL_FLAT && (p->flags & RT_FLAG_REGROUP) && regroup_fits) {
         rc = p->mode == RT_MODE_REF_EXACT ? launch_paths_regroup<RT_MODE_REF_EXACT>(h, p, film, total)
                                           : launch_paths_regroup<RT_MODE_BOOK3>(h, p, film, total);
     } else {

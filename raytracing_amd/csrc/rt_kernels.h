@@ -1383,24 +1383,32 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
 // ------------------------------------------------------------------ persistent path kernel, regrouping
 // Flat worlds.  The same loop as k_paths, but a path is not tied to a lane: every wave keeps a pool
 // of REGROUP_SLOTS paths in LDS and, per pool, one list of slot numbers for every kind of work a
-// path can be waiting for -- a camera ray to make (free slot), a closest hit to find, a scatter at
-// a diffuse / metal / glass vertex.  Each turn the wave takes up to 64 slots from the fullest
-// list and runs that one step for them, so the step's code runs with most lanes active instead of
-// the 10-20 of 64 that want it in a wave of lane-bound paths.  The pool belongs to one wave:
-// lists are pushed with ballot + mbcnt prefixes, there are no barriers and no atomics.  Every
-// random number is keyed by (pixel, stratum, bounce), so the image equals k_paths'.
+// path can be waiting for -- a closest hit to find, a scatter at a diffuse / metal / glass vertex,
+// its end (what a light or the background contributes, then a new camera ray into the same slot).
+// Each turn the wave takes up to 64 slots from the fullest list and runs that one step for them,
+// so the step's code runs with most lanes active instead of the 10-20 of 64 that want it in a
+// wave of lane-bound paths.  The pool belongs to one wave: lists are pushed with ballot + mbcnt
+// prefixes, there are no barriers and no atomics.  Every random number is keyed by
+// (pixel, stratum, bounce), so the image equals k_paths'.
 // Exit: a wave leaves when the sample counter has run out and every list but the free one is
 // empty; each step moves its slots on and a path ends within max_depth bounces.
 #ifndef RT_REGROUP_SLOTS
-#define RT_REGROUP_SLOTS 128
+#define RT_REGROUP_SLOTS 176
 #endif
 constexpr int REGROUP_SLOTS = RT_REGROUP_SLOTS;
-enum : uint32_t { RG_FREE = 0, RG_RAY = 1, RG_DIFFUSE = 2, RG_METAL = 3, RG_GLASS = 4, RG_LISTS = 5 };
+enum : uint32_t { RG_FREE = 0, RG_RAY = 1, RG_DIFFUSE = 2, RG_METAL = 3, RG_GLASS = 4, RG_END = 5, RG_LISTS = 6 };
+constexpr uint32_t RG_REF_NOTHING = 0xFFFFFFFEu; // in place of a hit's ref: the path ended with nothing to deposit
+// A slot is 52 bytes + 6 list bytes: the pool size sets how full the turns run (measured on the
+// Book-3 Cornell box: 96 slots 34.8, 128 42.0, 144 43.8 G segments/s), and 16 waves share 160 KB.
+//   ra: origin and time; once the closest hit is found, the hit point and time
+//   rb: direction and the ref of the primitive the ray leaves; once the hit is found, the hit's ref
+//   sa: throughput and pixel;  sb: stratum | bounce << 24
 struct RegroupPool {
-    float4 ra[REGROUP_SLOTS], rb[REGROUP_SLOTS], sa[REGROUP_SLOTS]; // as in k_paths
-    uint4 sh[REGROUP_SLOTS];                                        // stratum, bounce, t and ref of the hit to scatter at
+    float4 ra[REGROUP_SLOTS], rb[REGROUP_SLOTS], sa[REGROUP_SLOTS];
+    uint32_t sb[REGROUP_SLOTS];
     uint8_t list[RG_LISTS][REGROUP_SLOTS];
 };
+constexpr uint32_t REGROUP_MAX_STRATA = 1u << 24, REGROUP_MAX_DEPTH = 255u; // what sb holds
 static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE, "slot numbers are bytes");
 #ifndef RT_REGROUP_WAVES
 #define RT_REGROUP_WAVES 4
@@ -1422,7 +1430,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     for (uint32_t i = lane; i < uint32_t(REGROUP_SLOTS); i += WAVE) pool.list[RG_FREE][i] = uint8_t(i);
     // list lengths, wave-uniform
-    uint32_t n_free = REGROUP_SLOTS, n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0;
+    uint32_t n_free = REGROUP_SLOTS, n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0, n_end = 0;
     const unsigned long long total = ctrl->total_samples;
     unsigned long long next = 0, end = 0, seen = 0; // sample ids this wave owns; counter value at its last request
     const float inv_share = 1.0f / (4.0f * float(gridDim.x * (BLOCK / WAVE)));
@@ -1440,6 +1448,47 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         if (yes) pool.list[which][n + prefix] = uint8_t(slot);
         n += uint32_t(__popcll(mask));
     };
+    // up to `want` new samples from the wave's range (asking the counter for a new range when it
+    // is used up): lanes below the returned count make their camera ray (camera.rs:409-430) in
+    // `slot`, which joins the rays to trace
+    auto new_paths = [&](uint32_t want, uint32_t slot) -> uint32_t {
+        if (next == end && !exhausted) {
+            const float left = float(total > seen ? total - seen : 0ull);
+            uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
+            take = take < MIN_TAKE_FLAT ? MIN_TAKE_FLAT : (take & ~uint32_t(WAVE - 1));
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(take));
+            b = wave_first(b);
+            seen = b;
+            next = b < total ? b : total;
+            end = b + take < total ? b + take : total;
+            exhausted = next == end;
+            next_pixel = uint32_t(next % cam.npix);
+            next_stratum = cam.stratum_begin + uint32_t(next / cam.npix);
+        }
+        const uint32_t m = uint32_t(end - next < want ? end - next : want);
+        if (m == 0) return 0;
+        if (lane < m) {
+            uint32_t px = next_pixel + lane, st = next_stratum;
+            while (px >= cam.npix) px -= cam.npix, ++st;
+            Rng rng;
+            rng.begin(k0, k1, px, st, STREAM_CAMERA, 0);
+            V3 o, d;
+            float time;
+            camera_ray(cam, px, st, rng, o, d, time);
+            pool.ra[slot] = make_float4(o.x, o.y, o.z, time);
+            pool.rb[slot] = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
+            pool.sa[slot] = make_float4(1.f, 1.f, 1.f, bitsf(px));
+            pool.sb[slot] = st;
+            pool.list[RG_RAY][n_ray + lane] = uint8_t(slot);
+        }
+        n_ray += m;
+        next += m;
+        n_cam += m;
+        next_pixel += m;
+        while (next_pixel >= cam.npix) next_pixel -= cam.npix, ++next_stratum;
+        return m;
+    };
     for (;;) {
         // lanes of one wave run in step, so LDS written in one turn is read back in the next
         // without a barrier; the fence keeps the compiler from moving accesses across turns
@@ -1453,51 +1502,36 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         offer(RG_DIFFUSE, n_diffuse);
         offer(RG_GLASS, n_glass);
         offer(RG_METAL, n_metal);
+        offer(RG_END, n_end);
         if (!exhausted) offer(RG_FREE, n_free);
         if (most == 0) break;
 
         if (stage == RG_FREE) {
-            // camera rays for free slots (camera.rs:409-430)
-            if (next == end) {
-                const float left = float(total > seen ? total - seen : 0ull);
-                uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
-                take = take < MIN_TAKE_FLAT ? MIN_TAKE_FLAT : (take & ~uint32_t(WAVE - 1));
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(take));
-                b = wave_first(b);
-                seen = b;
-                next = b < total ? b : total;
-                end = b + take < total ? b + take : total;
-                exhausted = next == end;
-                next_pixel = uint32_t(next % cam.npix);
-                next_stratum = cam.stratum_begin + uint32_t(next / cam.npix);
-            }
-            const uint32_t m = uint32_t(end - next < most ? end - next : most);
-            if (m == 0) continue;
+            // slots that hold no path yet (the start of the frame)
+            const uint32_t slot = lane < most ? pool.list[RG_FREE][n_free - 1 - lane] : 0u;
+            const uint32_t m = new_paths(most, slot);
             RT_RG_COUNT(RG_FREE, m);
-            n_free -= m;
-            if (lane < m) {
-                const uint32_t slot = pool.list[RG_FREE][n_free + lane];
-                uint32_t px = next_pixel + lane, st = next_stratum;
-                while (px >= cam.npix) px -= cam.npix, ++st;
-                Rng rng;
-                rng.begin(k0, k1, px, st, STREAM_CAMERA, 0);
-                V3 o, d;
-                float time;
-                camera_ray(cam, px, st, rng, o, d, time);
-                pool.ra[slot] = make_float4(o.x, o.y, o.z, time);
-                pool.rb[slot] = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
-                pool.sa[slot] = make_float4(1.f, 1.f, 1.f, bitsf(px));
-                pool.sh[slot] = make_uint4(st, 0u, 0u, RT_REF_NONE);
-                pool.list[RG_RAY][n_ray + lane] = uint8_t(slot);
+            n_free -= m; // the first m lanes took the last m entries
+        } else if (stage == RG_END) {
+            // what the path's last hit contributes -- background or emission (camera.rs:445-453)
+            // -- and the next sample into the same slot
+            const uint32_t m = most;
+            RT_RG_COUNT(RG_END, m);
+            n_end -= m;
+            const bool active = lane < m;
+            uint32_t slot = 0;
+            if (active) {
+                slot = pool.list[RG_END][n_end + lane];
+                const float4 rb = pool.rb[slot];
+                if (fbits(rb.w) != RG_REF_NOTHING) {
+                    Surface sf; // ra holds the hit point: t = 0 from there
+                    (void)shade_emit(sc, cam, film, pool.ra[slot], rb, pool.sa[slot], make_float4(0.f, rb.w, 0.f, 0.f), true, sf);
+                }
             }
-            n_ray += m;
-            next += m;
-            n_cam += m;
-            next_pixel += m;
-            while (next_pixel >= cam.npix) next_pixel -= cam.npix, ++next_stratum;
+            const uint32_t taken = new_paths(m, slot);
+            push(RG_FREE, n_free, active && lane >= taken, slot); // no samples left: the slot stays empty
         } else if (stage == RG_RAY) {
-            // closest hit, and what the hit itself contributes (camera.rs:444-453)
+            // closest hit (camera.rs:444)
             const uint32_t m = most;
             RT_RG_COUNT(RG_RAY, m);
             n_ray -= m;
@@ -1509,8 +1543,8 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 const float4 ra = pool.ra[slot], rb = pool.rb[slot];
                 RayCtx rc{k0, k1, 0u, 0u, 0u};
                 if (has_media) { // a medium keys its free-flight draw by the sample and the bounce
-                    const uint4 sh = pool.sh[slot];
-                    rc.pixel = fbits(pool.sa[slot].w), rc.sample = sh.x, rc.bounce = sh.y;
+                    const uint32_t sb = pool.sb[slot];
+                    rc.pixel = fbits(pool.sa[slot].w), rc.sample = sb & 0xFFFFFFu, rc.bounce = sb >> 24;
                 }
                 Best best;
                 scan_flat(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
@@ -1523,17 +1557,14 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                                                                    : sc.media[idx].mat;
                     type = sc.mats[mat_id].type;
                 }
-                if (type == RT_MAT_LIGHT) {
-                    Surface sf;
-                    (void)shade_emit(sc, cam, film, ra, rb, pool.sa[slot], make_float4(best.t, bitsf(best.ref), 0.f, 0.f), true, sf);
-                    kind = RG_FREE;
-                } else {
-                    reinterpret_cast<uint2 *>(&pool.sh[slot])[1] = make_uint2(fbits(best.t), best.ref);
-                    kind = type == RT_MAT_METAL ? RG_METAL : (type == RT_MAT_DIELECTRIC ? RG_GLASS : RG_DIFFUSE);
-                }
+                const V3 p = fma3(mk(rb), best.t, mk(ra)); // as shade_emit forms it
+                pool.ra[slot] = make_float4(p.x, p.y, p.z, ra.w);
+                pool.rb[slot].w = bitsf(best.ref);
+                kind = type == RT_MAT_LIGHT ? RG_END
+                                            : (type == RT_MAT_METAL ? RG_METAL : (type == RT_MAT_DIELECTRIC ? RG_GLASS : RG_DIFFUSE));
             }
             push(RG_DIFFUSE, n_diffuse, kind == RG_DIFFUSE, slot);
-            push(RG_FREE, n_free, kind == RG_FREE, slot);
+            push(RG_END, n_end, kind == RG_END, slot);
             push(RG_GLASS, n_glass, kind == RG_GLASS, slot);
             push(RG_METAL, n_metal, kind == RG_METAL, slot);
         } else {
@@ -1549,10 +1580,10 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 if (active) {
                     slot = pool.list[stage][n_list + lane];
                     float4 ra = pool.ra[slot], rb = pool.rb[slot], sa = pool.sa[slot];
-                    const uint4 sh = pool.sh[slot];
-                    uint2 sb = make_uint2(sh.x, sh.y);
-                    Surface sf;
-                    (void)shade_emit<false>(sc, cam, film, ra, rb, sa, make_float4(bitsf(sh.z), bitsf(sh.w), 0.f, 0.f), true, sf);
+                    const uint32_t packed = pool.sb[slot];
+                    uint2 sb = make_uint2(packed & 0xFFFFFFu, packed >> 24);
+                    Surface sf; // ra holds the hit point: t = 0 from there
+                    (void)shade_emit<false>(sc, cam, film, ra, rb, sa, make_float4(0.f, rb.w, 0.f, 0.f), true, sf);
                     Rng rng;
                     rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
                     alive = shade_scatter<MODE, ONLY>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
@@ -1560,11 +1591,13 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                         pool.ra[slot] = ra;
                         pool.rb[slot] = rb;
                         pool.sa[slot] = sa;
-                        reinterpret_cast<uint2 *>(&pool.sh[slot])[0] = sb;
+                        pool.sb[slot] = sb.x | (sb.y << 24);
+                    } else {
+                        pool.rb[slot].w = bitsf(RG_REF_NOTHING);
                     }
                 }
                 push(RG_RAY, n_ray, alive, slot);
-                push(RG_FREE, n_free, active && !alive, slot);
+                push(RG_END, n_end, active && !alive, slot);
             };
             if (stage == RG_DIFFUSE) scatter_turn(std::integral_constant<uint32_t, RT_MAT_LAMBERTIAN>{}, n_diffuse);
             else if (stage == RG_GLASS) scatter_turn(std::integral_constant<uint32_t, RT_MAT_DIELECTRIC>{}, n_glass);
