@@ -97,7 +97,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-strata", type=int, default=6, help="strata of the full frame the CPU baseline renders")
     ap.add_argument("--wavefront", action="store_true", help="ray-queue pipeline instead of the persistent path kernel")
-    ap.add_argument("--regroup", action="store_true", help="persistent kernel with per-wave regrouping of paths (flat worlds)")
+    ap.add_argument("--regroup", choices=["auto", "on", "off"], default="auto",
+                    help="persistent kernel on a flat world: paths regrouped per wave by the step they wait for, or lane-bound")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU machine: every rank uses GPU 0 (needs --backend gloo); the line is marked")
@@ -131,8 +132,8 @@ def main():
         torch.cuda.synchronize()
 
     extra = dict(wavefront=True, pool_size=args.pool, time_every=8) if args.wavefront else {}
-    if args.regroup:
-        extra["regroup"] = True
+    if args.regroup != "auto":
+        extra["regroup"] = args.regroup == "on"
     for _ in range(args.warmup):
         renderer.render(rcam, n_strata, rank, world, mode, seed=1, **extra)
     barrier()
@@ -141,6 +142,7 @@ def main():
     launches = np.zeros(5)
     timed = np.zeros(5)
     cam_rays = 0
+    regrouped = False
     t0 = time.perf_counter()
     for step in range(args.steps):
         # kernels are bracketed by HIP events on the stream they run on: the one launch of the
@@ -150,6 +152,7 @@ def main():
         if st is not None:
             seg += st.segments
             cam_rays += st.camera_rays
+            regrouped = st.regrouped
             kernel_ms += np.array(st.kernel_ms)
             timed += np.array(st.timed_launches)
             launches += np.array(st.launches)
@@ -188,7 +191,7 @@ def main():
         **({"rehearsal": "all ranks share GPU 0; not a scaling measurement"} if args.share_gpu else {}),
         "config": {"workload": desc, "name": args.workload, "image": [cam.image_width, cam.image_height],
                    "spp": n_strata, "max_depth": cam.max_depth, "estimator": "book3" if mode == ra.RT_MODE_BOOK3 else "ref-exact",
-                   "pipeline": "wavefront" if args.wavefront else "persistent",
+                   "pipeline": "wavefront" if args.wavefront else ("persistent, paths regrouped per wave" if regrouped else "persistent"),
                    "parallelism": f"spp-split x{world}, one fp32 film all-reduce per step",
                    "segments_per_step": int(total_seg / args.steps), "segments_per_camera_ray": round(total_seg / max(total_cam, 1), 3)},
         "time_to_1000spp_s": round(ms_per_step * 1e-3 * 1000.0 / n_strata, 4),
@@ -214,7 +217,7 @@ def main():
     # the fp32 vector peak.  achieved = algorithmic flops per segment (reference arithmetic,
     # FMA = 2, counted by the oracle) x segments per launch / the kernel's launch duration.
     if fps:
-        kernel_name = "k_" + names[k]
+        kernel_name = "k_paths_regroup" if (names[k] == "paths" and regrouped) else "k_" + names[k]
         tflops = fps * seg_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         if names[k] != "paths":
             # a segment's arithmetic is spread over the four wavefront kernels: price them together

@@ -167,8 +167,15 @@ typedef struct {
 #define RT_FLAG_TIME_KERNELS 1u /* bracket kernels with HIP events (see rt_stats) */
 #define RT_FLAG_WAVEFRONT 2u    /* ray-queue pipeline (scan/generate/extend/shade launches) instead of
                                  * the persistent path kernel; same image for the same seed */
-#define RT_FLAG_REGROUP 4u      /* persistent kernel, flat worlds: paths regrouped by the step they wait for
-                                 * (per-wave pools in LDS) instead of one path per lane; same image */
+/* Persistent kernel on a flat world (one list of primitives): either every lane carries one path
+ * from its camera ray to its end, or every wave keeps a pool of paths in LDS and regroups them
+ * by the step they wait for (closest hit, scatter at a diffuse / metal / glass vertex, end), so
+ * that each step runs with most lanes active.  Same image either way.  Default: regrouping for
+ * RT_MODE_BOOK3 (measured 28 % faster on the Book-3 Cornell box), lane-bound paths for
+ * RT_MODE_REF_EXACT (one kind of scatter, paths of about two segments: 2 % faster lane-bound).
+ * Regrouping needs sqrt_spp <= 4096 and max_depth <= 255 and falls back otherwise. */
+#define RT_FLAG_REGROUP 4u
+#define RT_FLAG_NO_REGROUP 8u
 typedef struct {
     uint32_t mode;
     uint32_t flags;
@@ -189,6 +196,7 @@ typedef struct {
     uint64_t timed_launches[5]; /* launches bracketed by HIP events (RT_FLAG_TIME_KERNELS) */
     double kernel_ms[5];   /* summed HIP-event time of the timed launches, per kernel */
     double render_ms;      /* HIP-event time of the last rt_render, first launch to last */
+    uint64_t regrouped;    /* 1 if the last rt_render ran the regrouping variant of the persistent kernel */
 } rt_stats;
 
 typedef struct rt_handle rt_handle;

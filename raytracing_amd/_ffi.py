@@ -70,7 +70,8 @@ class RtRenderParams(C.Structure):
 
 class RtStats(C.Structure):
     _fields_ = [("segments", u64), ("camera_rays", u64), ("dropped", u64), ("iterations", u64),
-                ("launches", u64 * 5), ("timed_launches", u64 * 5), ("kernel_ms", f64 * 5), ("render_ms", f64)]
+                ("launches", u64 * 5), ("timed_launches", u64 * 5), ("kernel_ms", f64 * 5), ("render_ms", f64),
+                ("regrouped", u64)]
 
 
 class CameraBuilderStruct(C.Structure):
@@ -91,6 +92,7 @@ RT_BUILD_REFERENCE, RT_BUILD_SAH, RT_BUILD_AUTO = 0, 1, 2
 RT_FLAG_TIME_KERNELS = 1
 RT_FLAG_WAVEFRONT = 2
 RT_FLAG_REGROUP = 4
+RT_FLAG_NO_REGROUP = 8
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
 RT_NODE_LEAF = 0xFFFFFFFF
 

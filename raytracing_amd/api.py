@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _ffi
-from ._ffi import (CameraBuilderStruct, RtCamera, RtRenderParams, RtSceneDesc, RtStats, RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT, RT_FLAG_REGROUP,
+from ._ffi import (CameraBuilderStruct, RtCamera, RtRenderParams, RtSceneDesc, RtStats, RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT, RT_FLAG_REGROUP, RT_FLAG_NO_REGROUP,
                    RT_MODE_BOOK3, RT_MODE_REF_EXACT)
 
 SHAPE_PARALLELOGRAM, SHAPE_TRIANGLE, SHAPE_DISC = 0, 1, 2
@@ -240,6 +240,7 @@ class Stats:
     timed_launches: tuple = (0, 0, 0, 0, 0)
     kernel_ms: tuple = (0.0, 0.0, 0.0, 0.0, 0.0)  # HIP-event time of the timed launches
     render_ms: float = 0.0
+    regrouped: bool = False  # the persistent kernel ran in its regrouping variant
 
 
 class Device:
@@ -303,13 +304,15 @@ class Device:
         self._check(self.lib.rt_film_clear(self.h), "rt_film_clear")
 
     def render(self, cam: RtCamera, mode=RT_MODE_REF_EXACT, seed=1, stratum_begin=0, stratum_end=0, pool_size=0,
-               time_kernels=False, time_every=0, wavefront=False, refill_min=0, waves_per_simd=0, regroup=False):
+               time_kernels=False, time_every=0, wavefront=False, refill_min=0, waves_per_simd=0, regroup=None):
         """Adds strata [begin, end) of every pixel into the film (camera.rs:386-401).
-        wavefront=True takes the ray-queue pipeline instead of the persistent path kernel."""
+        wavefront=True takes the ray-queue pipeline instead of the persistent path kernel.
+        regroup: True / False forces the persistent kernel's regrouping or lane-bound variant on a
+        flat world, None leaves the choice to the library."""
         p = RtRenderParams()
         p.mode, p.seed = mode, seed
         p.flags = (RT_FLAG_TIME_KERNELS if time_kernels else 0) | (RT_FLAG_WAVEFRONT if wavefront else 0) | \
-            (RT_FLAG_REGROUP if regroup else 0)
+            (0 if regroup is None else (RT_FLAG_REGROUP if regroup else RT_FLAG_NO_REGROUP))
         p.refill_min, p.waves_per_simd = refill_min, waves_per_simd
         p.stratum_begin, p.stratum_end, p.pool_size, p.time_every = stratum_begin, stratum_end, pool_size, time_every
         self._check(self.lib.rt_render(self.h, C.byref(cam), C.byref(p)), "rt_render")
@@ -320,7 +323,7 @@ class Device:
         s = RtStats()
         self._check(self.lib.rt_get_stats(self.h, C.byref(s)), "rt_get_stats")
         return Stats(s.segments, s.camera_rays, s.dropped, s.iterations, tuple(s.launches), tuple(s.timed_launches),
-                     tuple(s.kernel_ms), s.render_ms)
+                     tuple(s.kernel_ms), s.render_ms, bool(s.regrouped))
 
     def film(self, scale=1.0):
         """(H, W, 3) float32 = film sums * scale."""

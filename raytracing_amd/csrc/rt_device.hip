@@ -364,6 +364,7 @@ int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &fi
     tm.end(e);
     RT_HIP(hipGetLastError());
     h->stats.launches[4]++;
+    h->stats.regrouped = 1;
     return 0;
 }
 
@@ -373,7 +374,8 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     int rc;
     // the regrouping kernel packs stratum and bounce into one word
     const bool regroup_fits = dc.sqrt_spp <= 4096u && dc.max_depth <= REGROUP_MAX_DEPTH;
-    if (h->accel == ACCEL_FLAT && (p->flags & RT_FLAG_REGROUP) && regroup_fits) {
+    const bool regroup_wanted = (p->flags & RT_FLAG_REGROUP) || (!(p->flags & RT_FLAG_NO_REGROUP) && p->mode == RT_MODE_BOOK3);
+    if (h->accel == ACCEL_FLAT && regroup_wanted && regroup_fits) {
         rc = p->mode == RT_MODE_REF_EXACT ? launch_paths_regroup<RT_MODE_REF_EXACT>(h, p, film, total)
                                           : launch_paths_regroup<RT_MODE_BOOK3>(h, p, film, total);
     } else {

@@ -231,15 +231,28 @@ def test_intersection_golden_fixture(device):
         assert np.quantile(np.abs(t[ok] - g["t"][ok]) / g["t"][ok], 0.995) < 1e-5
 
 
-@pytest.mark.parametrize("wavefront", [False, True], ids=["persistent", "wavefront"])
+# The ways one frame can be rendered: the persistent kernel as the library chooses it, its two
+# variants on a flat world forced (a path per lane / paths regrouped per wave by the step they
+# wait for), and the ray-queue pipeline.  All draw the same random numbers.
+PIPELINES = {"persistent": {}, "lane-bound": dict(regroup=False), "regrouped": dict(regroup=True), "wavefront": dict(wavefront=True)}
+FLAT_WORLDS = ("c1", "c3")
+
+
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
 @pytest.mark.parametrize("name,med,frac", [("c1", 1e-5, 0.01), ("c3", 1e-4, 0.06), ("c2", 1e-4, 0.08), ("c4", 1e-4, 0.08), ("c5", 1e-4, 0.10)])
-def test_render_same_stream_pixelwise(device, name, med, frac, wavefront):
+def test_render_same_stream_pixelwise(device, name, med, frac, pipeline):
     """Same uniforms on both sides: almost every pixel agrees to fp32 accuracy; the few that do
     not are paths that forked at an fp32-vs-f64 decision (edge, rejection loop, Schlick draw)."""
+    if pipeline in ("lane-bound", "regrouped") and name not in FLAT_WORLDS:
+        pytest.skip("the persistent kernel has one variant behind a BVH")
     host, osb, cam, mode, _ = scene(name, device)
     rc = cam.build()
     device.film_resize(cam.image_width, cam.image_height)
-    st = device.render(rc, mode=mode, seed=1, wavefront=wavefront)
+    st = device.render(rc, mode=mode, seed=1, **PIPELINES[pipeline])
+    if pipeline in ("lane-bound", "regrouped"):
+        assert st.regrouped == (pipeline == "regrouped")
+    if pipeline == "persistent":  # the library's choice: regrouping on a flat world under the mixture estimator
+        assert st.regrouped == (name in FLAT_WORLDS and mode == ra.RT_MODE_BOOK3)
     gpu = device.film(1.0 / cam.effective_spp)
     film, _, cnt = orc.render(osb, cam, mode=mode, seed=1)
     cpu = film / cam.effective_spp
@@ -345,14 +358,14 @@ def test_strata_split_and_pool_size_do_not_change_the_image(device):
     # identical sample sets; only the fp32 summation order differs
     assert np.allclose(parts, whole, rtol=2e-5, atol=1e-5)
     # neither does the pipeline, the number of rays in flight or the refill policy
-    variants = [dict(wavefront=True), dict(wavefront=True, pool_size=2048), dict(refill_min=1),
-                dict(refill_min=64, waves_per_simd=1), dict()]
+    variants = [dict(wavefront=True), dict(wavefront=True, pool_size=2048), dict(refill_min=1, regroup=False),
+                dict(refill_min=64, waves_per_simd=1, regroup=False), dict(waves_per_simd=2), dict()]
     for kw in variants:
         device.film_clear()
         st = device.render(rc, mode=mode, seed=4, **kw)
         img = device.film().astype(np.float64)
-        if kw.get("wavefront"):
-            # the two pipelines are separate compilations of the same source: a last-bit
+        if kw.get("wavefront") or kw.get("regroup") is False:
+            # the kernels are separate compilations of the same source: a last-bit
             # difference (fma contraction) can fork a path at a comparison, in a few pixels
             off = ~np.isclose(img, whole, rtol=2e-5, atol=1e-5)
             assert off.mean() < 0.01, (kw, off.mean())
@@ -478,8 +491,8 @@ def test_textures_on_device_match_oracle(device):
             assert bad.mean() < 2e-3, (name, bad.sum())
 
 
-@pytest.mark.parametrize("wavefront", [False, True], ids=["persistent", "wavefront"])
-def test_image_textured_quads_in_a_flat_world(device, wavefront):
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
+def test_image_textured_quads_in_a_flat_world(device, pipeline):
     """The flat scan does not carry a quad's (alpha, beta) through its loop; a material that looks
     at them (an image texture, also nested in a checker and on an emitter) gets them recomputed
     from the hit point.  Same-stream render of a one-list world against the oracle, and the
@@ -501,7 +514,7 @@ def test_image_textured_quads_in_a_flat_world(device, wavefront):
     device.upload(host)
     assert device.accel_info()["kind"] == "flat"
     device.film_resize(48, 48)
-    device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=3, wavefront=wavefront)
+    device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=3, **PIPELINES[pipeline])
     gpu = device.film(1.0 / 16)
     film, _, _ = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=3)
     r = helpers.compare_same_stream(gpu, film / 16)
@@ -675,8 +688,8 @@ def test_render_from_a_scene_file_matches_the_oracle_reading_the_same_file(devic
     assert st3.camera_rays == 96 * 96 * 4 and np.isfinite(device.film()).all() and device.film().mean() > 0
 
 
-@pytest.mark.parametrize("wavefront", [False, True], ids=["persistent", "wavefront"])
-def test_edge_sizes(device, wavefront):
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
+def test_edge_sizes(device, pipeline):
     """Empty, tiny and ragged inputs: an empty ray batch, the smallest image CameraBuilder
     accepts (2x2, camera.rs:105-116), sizes that are not a multiple of the 64-lane wave or of the
     4-pixel packing of the output stage, one sample per pixel, an empty stratum range, fewer
@@ -688,7 +701,7 @@ def test_edge_sizes(device, wavefront):
         c = ra.CameraSettings(**{**cam.__dict__, "image_width": w, "image_height": h, "samples_per_px": spp})
         oc = ra.CameraSettings(**{**cam.__dict__, "image_width": w, "image_height": h, "samples_per_px": spp})
         device.film_resize(w, h)
-        st = device.render(c.build(), mode=mode, seed=3, wavefront=wavefront)
+        st = device.render(c.build(), mode=mode, seed=3, **PIPELINES[pipeline])
         film, _, cnt = orc.render(osb, oc, mode=mode, seed=3)
         assert st.camera_rays == w * h * c.effective_spp == cnt["camera_rays"]
         gpu = device.film(1.0 / c.effective_spp)
@@ -699,10 +712,33 @@ def test_edge_sizes(device, wavefront):
     # an empty stratum range renders nothing and leaves the film alone
     device.film_resize(8, 8)
     c = ra.CameraSettings(**{**cam.__dict__, "image_width": 8, "image_height": 8, "samples_per_px": 16})
-    st = device.render(c.build(), mode=mode, seed=3, stratum_begin=5, stratum_end=5, wavefront=wavefront)
+    st = device.render(c.build(), mode=mode, seed=3, stratum_begin=5, stratum_end=5, **PIPELINES[pipeline])
     assert st.camera_rays == 0 and st.segments == 0 and not device.film().any()
     with pytest.raises(ra.RtError, match="greater than 1"):
         ra.CameraSettings(**{**cam.__dict__, "image_width": 1, "image_height": 1}).build()
+
+
+def test_regrouping_kernel_equals_the_lane_bound_one(device):
+    """Both variants of the persistent kernel trace the same sample set: equal camera ray counts,
+    segment counts and films equal up to the order of the fp32 additions, for the shipped estimator
+    (single light, one list of quads) and the mixture estimator (light list, glass).  A depth
+    beyond what a regrouping slot holds (255) falls back to the lane-bound kernel."""
+    for name in FLAT_WORLDS:
+        host, osb, cam, mode, _ = scene(name, device)
+        c = ra.CameraSettings(**{**cam.__dict__, "image_width": 96, "image_height": 80, "samples_per_px": 25})
+        device.film_resize(96, 80)
+        out = {}
+        for regroup in (False, True):
+            device.film_clear()
+            st = device.render(c.build(), mode=mode, seed=7, regroup=regroup)
+            assert st.regrouped == regroup
+            out[regroup] = (st, device.film(1.0 / c.effective_spp).astype(np.float64))
+        (a, fa), (b, fb) = out[False], out[True]
+        # separate compilations of the same source: a last-bit difference may fork a path or two
+        assert a.camera_rays == b.camera_rays and abs(a.segments - b.segments) <= 1e-3 * a.segments
+        assert (~np.isclose(fa, fb, rtol=1e-4, atol=1e-5)).mean() < 0.01
+        deep = ra.CameraSettings(**{**c.__dict__, "max_depth": 300})
+        assert not device.render(deep.build(), mode=mode, seed=7, regroup=True).regrouped
 
 
 def test_maximum_sizes(device):
