@@ -223,7 +223,9 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *scene);
  *           grouping, RT_BUILD_SAH regroups all primitives by a binned surface-area heuristic,
  *           RT_BUILD_AUTO builds both and keeps the cheaper by surface-area cost;
  *   width 2: the descriptor's nodes traversed as they are (near child first).
- * A world that is one short list of primitives is scanned without any tree either way. */
+ * A world that is one short list of primitives is scanned without any tree either way; boxes
+ * at the end of its quads (main.rs:52-69) are recognised and tested as boxes, with the hit
+ * reported on the face's own quad. */
 #define RT_BUILD_REFERENCE 0u
 #define RT_BUILD_SAH 1u
 #define RT_BUILD_AUTO 2u /* both, keep the lower surface-area cost */
@@ -233,6 +235,9 @@ typedef struct {
     uint32_t nodes, depth;  /* of the structure searched (depth: wide only) */
     uint32_t stack_entries; /* per-lane traversal stack held in LDS */
     double cost;            /* wide only: expected box tests of a random ray through the root box */
+    uint32_t flat_quads;    /* flat only: quads tested one by one */
+    uint32_t flat_boxes;    /* flat only: runs of six quads at the end of the list that are the faces of one
+                             * rectangular box (box3, hittable.rs:398-455) and take one slab test each */
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 /* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it

@@ -283,6 +283,94 @@ int ensure_film(rt_handle *h, uint32_t w, uint32_t hgt) {
     return 0;
 }
 
+// Six parallelograms that are the faces of one rectangular box -- what box3 builds
+// (hittable.rs:398-455), under any rigid map: a frame, the two plane offsets per axis measured
+// from the centre, and the faces' refs by (axis, side).  Record layout: scan_flat.
+bool match_box(const rt_quad *const q[6], const uint32_t refs[6], float rec[32]) {
+    typedef double D3[3];
+    auto dot3 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto len3 = [&](const double *a) { return std::sqrt(dot3(a, a)); };
+    D3 centre[6], c = {0, 0, 0};
+    double extent = 0, reach = 0;
+    for (int i = 0; i < 6; ++i) {
+        if (q[i]->shape != RT_SHAPE_PARALLELOGRAM) return false;
+        D3 u = {q[i]->u[0], q[i]->u[1], q[i]->u[2]}, v = {q[i]->v[0], q[i]->v[1], q[i]->v[2]};
+        const double lu = len3(u), lv = len3(v);
+        if (!(lu > 0 && lv > 0) || std::fabs(dot3(u, v)) > 1e-6 * lu * lv) return false; // a rectangle
+        for (int a = 0; a < 3; ++a) {
+            centre[i][a] = q[i]->q[a] + 0.5 * (u[a] + v[a]);
+            c[a] += centre[i][a] / 6.0;
+            reach = std::max(reach, std::fabs(double(q[i]->q[a])));
+        }
+        extent = std::max(extent, std::max(lu, lv));
+    }
+    const double tol = 1e-5 * (extent + reach); // the records are fp32: corners carry ~1e-7 relative
+    D3 e[3];
+    {
+        const D3 u0 = {q[0]->u[0], q[0]->u[1], q[0]->u[2]}, v0 = {q[0]->v[0], q[0]->v[1], q[0]->v[2]};
+        const double lu = len3(u0), lv = len3(v0);
+        for (int a = 0; a < 3; ++a) e[0][a] = q[0]->u[a] / lu, e[1][a] = q[0]->v[a] / lv;
+        e[2][0] = e[0][1] * e[1][2] - e[0][2] * e[1][1];
+        e[2][1] = e[0][2] * e[1][0] - e[0][0] * e[1][2];
+        e[2][2] = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+    }
+    double plane[3][2], span[3][2][2];
+    bool seen[3][2] = {};
+    uint32_t face_ref[3][2];
+    for (int i = 0; i < 6; ++i) {
+        D3 m = {centre[i][0] - c[0], centre[i][1] - c[1], centre[i][2] - c[2]};
+        double along[3];
+        int k = 0;
+        for (int a = 0; a < 3; ++a) {
+            along[a] = dot3(m, e[a]);
+            if (std::fabs(along[a]) > std::fabs(along[k])) k = a;
+        }
+        const int side = along[k] > 0 ? 1 : 0;
+        if (seen[k][side] || std::fabs(along[k]) <= tol) return false;
+        for (int a = 0; a < 3; ++a)
+            if (a != k && std::fabs(along[a]) > tol) return false; // the face is centred on its axis
+        D3 n = {q[i]->n[0], q[i]->n[1], q[i]->n[2]};
+        if (std::fabs(std::fabs(dot3(n, e[k])) - 1.0) > 1e-6) return false;
+        // its edges run along the two other axes
+        D3 u = {q[i]->u[0], q[i]->u[1], q[i]->u[2]}, v = {q[i]->v[0], q[i]->v[1], q[i]->v[2]};
+        const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
+        const double u1 = std::fabs(dot3(u, e[a1])), u2 = std::fabs(dot3(u, e[a2]));
+        const double v1 = std::fabs(dot3(v, e[a1])), v2 = std::fabs(dot3(v, e[a2]));
+        const bool u_on_1 = u1 >= u2;
+        if ((u_on_1 ? u2 : u1) > tol || (u_on_1 ? v1 : v2) > tol) return false;
+        span[k][side][0] = u_on_1 ? u1 : v1; // extent along a1
+        span[k][side][1] = u_on_1 ? v2 : u2; // extent along a2
+        D3 rel = {q[i]->q[0] - c[0], q[i]->q[1] - c[1], q[i]->q[2] - c[2]};
+        plane[k][side] = dot3(rel, e[k]); // a point of the face's own plane
+        seen[k][side] = true;
+        face_ref[k][side] = refs[i];
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (!seen[k][0] || !seen[k][1] || !(plane[k][0] < plane[k][1])) return false;
+        const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
+        for (int side = 0; side < 2; ++side) // every face spans the box in its two directions
+            if (std::fabs(span[k][side][0] - (plane[a1][1] - plane[a1][0])) > 2 * tol ||
+                std::fabs(span[k][side][1] - (plane[a2][1] - plane[a2][0])) > 2 * tol)
+                return false;
+    }
+    std::fill(rec, rec + 32, 0.0f);
+    for (int k = 0; k < 3; ++k) {
+        for (int a = 0; a < 3; ++a) rec[3 * k + a] = float(e[k][a]);
+        rec[9 + k] = float(c[k]);
+        std::memcpy(&rec[18 + k], &face_ref[k][0], 4);
+        std::memcpy(&rec[21 + k], &face_ref[k][1], 4);
+    }
+    // offsets from the centre as fp32 stores it, along the frame as fp32 stores it
+    for (int k = 0; k < 3; ++k)
+        for (int side = 0; side < 2; ++side) {
+            const int i = int(std::find(refs, refs + 6, face_ref[k][side]) - refs);
+            double off = 0;
+            for (int a = 0; a < 3; ++a) off += (double(q[i]->q[a]) - double(rec[9 + a])) * double(rec[3 * k + a]);
+            rec[(side ? 15 : 12) + k] = float(off);
+        }
+    return true;
+}
+
 // timed launch helper
 struct Timer {
     rt_handle *h;
@@ -527,8 +615,8 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     }
     // A world that is one list of primitives takes the stack-free scan: its quads packed in
     // list order for scalar loads, everything else by reference.
-    std::vector<float> flat_quads;
-    std::vector<uint32_t> flat_other;
+    std::vector<float> flat_quads, flat_boxes;
+    std::vector<uint32_t> flat_other, flat_quad_refs;
     h->flat = false;
     {
         uint32_t rk = s->root >> RT_REF_KIND_SHIFT, ri = s->root & RT_REF_INDEX_MASK;
@@ -551,7 +639,23 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
                     std::memcpy(&rec[7], &q.mat, 4);
                     std::memcpy(&rec[11], &q.shape, 4);
                     flat_quads.insert(flat_quads.end(), rec, rec + 16);
+                    flat_quad_refs.push_back(r);
                 }
+                // Boxes at the end of the quads (main.rs:52-69 lists walls, light, boxes) leave the
+                // quad records for one slab test each.  Only from the end: the scan takes quads
+                // first, then boxes, and a later quad wins a tie (a box standing on the floor).
+                std::vector<float> found;
+                while (flat_quad_refs.size() >= 6) {
+                    const size_t first = flat_quad_refs.size() - 6;
+                    const rt_quad *faces[6];
+                    for (int i = 0; i < 6; ++i) faces[i] = &s->quads[flat_quad_refs[first + i] & RT_REF_INDEX_MASK];
+                    float rec[32];
+                    if (!match_box(faces, &flat_quad_refs[first], rec)) break;
+                    found.insert(found.begin(), rec, rec + 32);
+                    flat_quad_refs.resize(first);
+                    flat_quads.resize(first * 16);
+                }
+                flat_boxes = found;
             }
         }
     }
@@ -617,7 +721,8 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     // the scan requests records in pairs, one pair ahead: pad with records that cannot hit
     flat_quads.resize((size_t(d.n_flat_quads) + 3) / 2 * 2 * 16, 0.0f);
     d.n_flat_other = uint32_t(flat_other.size());
-    if (upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
+    d.n_flat_boxes = uint32_t(flat_boxes.size() / 32);
+    if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, s->spheres, s->n_spheres, &ds) ||
         upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || upload(h, nodes4.data(), nodes4.size(), &dn4) ||
         upload(h, flat_other.data(), flat_other.size(), &d.flat_other) ||
@@ -684,6 +789,7 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
     if (out) {
         out->kind = uint32_t(ACCEL_BVH4);
         out->nodes = st.nodes, out->depth = st.depth, out->stack_entries = st.stack_need, out->cost = st.cost;
+        out->flat_quads = out->flat_boxes = 0;
     }
     return 0;
 }
@@ -696,6 +802,8 @@ int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     out->depth = h->accel == ACCEL_BVH4 ? h->accel_stats.depth : 0u;
     out->stack_entries = h->accel == ACCEL_BVH4 ? h->stack4 : (h->accel == ACCEL_BVH2 ? uint32_t(STACK_DEPTH) : 0u);
     out->cost = h->accel == ACCEL_BVH4 ? h->accel_stats.cost : 0.0;
+    out->flat_quads = h->accel == ACCEL_FLAT ? h->sc.n_flat_quads : 0u;
+    out->flat_boxes = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes : 0u;
     return 0;
 }
 

@@ -64,9 +64,12 @@ struct DScene {
     const float *flat_quads;
     const float *flat_pairs; // the same quads two per record when all are parallelograms (see scan_flat)
     const uint32_t *flat_other;
+    // runs of six quads at the end of the list's quads that are the faces of one rectangular box
+    // (box3, hittable.rs:398-455, under any rigid map): 32 floats each, see scan_flat
+    const float *flat_boxes;
     // 4-wide BVH derived at upload (rt_accel.h): 8 float4 per node, root = node 0
     const float4 *nodes4;
-    uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_pairs, n_flat_other, n_nodes4;
+    uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_pairs, n_flat_other, n_nodes4, n_flat_boxes;
     // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
     uint32_t stack4, lds_nodes4;
 };
@@ -651,6 +654,42 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
             test(b);
         }
     }
+    // Boxes: six parallelograms that are the faces of one rectangular box cost one slab test in
+    // the box's frame (~65 vector instructions) instead of three pairs (135).  The ray crosses the
+    // faces' planes where the six quad tests put their hits -- t = (plane - e.o) / (e.d) with the
+    // face normal +-e -- and of a convex box only the first crossing past tlo can be the closest
+    // hit: the entry face, or the exit face for a ray that starts inside or on the entry face.
+    //   record, 32 floats: frame e0 e1 e2, centre c, plane offsets lo[3] hi[3] (along e_k, from c),
+    //   refs of the lo faces [3] and of the hi faces [3]
+    const RT_CONST_AS float *B = as_uniform(sc.flat_boxes);
+    for (uint32_t k = 0; k < sc.n_flat_boxes; ++k, B += 32) {
+        const V3 oc = {o.x - B[9], o.y - B[10], o.z - B[11]};
+        float t_lo[3], t_hi[3];
+        uint32_t r_in[3], r_out[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const V3 e = {B[3 * a], B[3 * a + 1], B[3 * a + 2]};
+            const float od = dot(e, oc), dd = dot(e, d), inv = __builtin_amdgcn_rcpf(dd);
+            const float ta = (B[12 + a] - od) * inv, tb = (B[15 + a] - od) * inv;
+            t_lo[a] = fminf(ta, tb), t_hi[a] = fmaxf(ta, tb);
+            const bool up = dd > 0.0f; // enters through the lo face, leaves through the hi face
+            const uint32_t rl = fbits(B[18 + a]), rh = fbits(B[21 + a]);
+            r_in[a] = up ? rl : rh, r_out[a] = up ? rh : rl;
+        }
+        const float t_near = fmaxf(fmaxf(t_lo[0], t_lo[1]), t_lo[2]), t_far = fminf(fminf(t_hi[0], t_hi[1]), t_hi[2]);
+        const uint32_t near_ref = t_lo[0] >= fmaxf(t_lo[1], t_lo[2]) ? r_in[0] : (t_lo[1] >= t_lo[2] ? r_in[1] : r_in[2]);
+        const uint32_t far_ref = t_hi[0] <= fminf(t_hi[1], t_hi[2]) ? r_out[0] : (t_hi[1] <= t_hi[2] ? r_out[1] : r_out[2]);
+        const bool use_near = (t_near >= tlo) & (near_ref != origin_ref);
+        const float tc = use_near ? t_near : t_far;
+        const uint32_t rcand = use_near ? near_ref : far_ref;
+        // A later quad wins a tie (t <= closest, hittable.rs:252-264), and ties happen: a box
+        // stands on the floor, its bottom face in the floor's plane.  The quad records give such
+        // a pair the same t to the bit; the slab arithmetic differs from theirs in the last
+        // bits, so the tie is taken within 4 ulp.
+        const bool ok = (t_near <= t_far) & (tc >= tlo) & (tc <= best.t * (1.0f + 0x1p-21f)) & (rcand != origin_ref);
+        best.t = ok ? tc : best.t;
+        best.ref = ok ? rcand : best.ref;
+    }
     const RT_CONST_AS uint32_t *other = as_uniform(sc.flat_other);
     for (uint32_t k = 0; k < sc.n_flat_other; ++k) test_prim<true>(sc, other[k], o, d, time, tlo, origin_ref, rc, best);
 }
@@ -1190,7 +1229,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, const DScene *scp, con
     const uint32_t n = q.count[chunk];
     if (n == 0) return;
     const size_t cbase = size_t(chunk) * q.cap;
-    const bool flat_world = (sc.n_flat_pairs | sc.n_flat_quads | sc.n_flat_other) != 0; // hits may come from the flat scan
+    const bool flat_world = (sc.n_flat_pairs | sc.n_flat_quads | sc.n_flat_other | sc.n_flat_boxes) != 0; // hits may come from the flat scan
     uint32_t out = 0; // survivors written so far; always <= base, so writes never pass reads
     for (uint32_t base = 0; base < n; base += WAVE) {
         const uint32_t k = base + lane;

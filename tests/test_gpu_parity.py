@@ -527,6 +527,76 @@ def test_image_textured_quads_in_a_flat_world(device, pipeline):
     assert same.mean() > 0.5 and np.abs(u[same] - u2[same]).max() < 1e-4 and np.abs(v[same] - v2[same]).max() < 1e-4
 
 
+def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device):
+    """A flat world's trailing box3 runs take one slab test per box.  The hits are the quad
+    tests' hits: a world with its boxes last (recognised) and the same world with a quad moved
+    behind them (every face tested as a quad) give the same primitive and t for rays from
+    outside, from inside a box, off a face (origin_prim set) and grazing, and both agree with the
+    oracle.  A box standing on the floor shares its bottom plane with it: the later primitive
+    wins the tie, as in HittableVec::hit."""
+    def build(sb, boxes_last):
+        white = sb.lambertian(sb.tex_solid(0.7, 0.7, 0.7))
+        floor = sb.quad((-6, 0, -6), (12, 0, 0), (0, 0, 12), white)
+        wall = sb.quad((-6, 0, -6), (12, 0, 0), (0, 8, 0), white)
+        lamp = sb.quad((-1, 7.9, -1), (2, 0, 0), (0, 0, 2), sb.light(sb.tex_solid(9, 9, 9)))
+        b1 = sb.translate(sb.rotate_y(sb.box3((0, 0, 0), (2, 3, 2), white), 20.0), (-3.5, 0, -1))
+        b2 = sb.translate(sb.rotate_y(sb.box3((0, 0, 0), (1.5, 1.5, 1.5), white), -33.0), (1.5, 0, 0.5))
+        b3 = sb.box3((-0.5, 2.0, -4.0), (0.5, 2.5, -3.0), white)  # axis-aligned, off the floor
+        objs = [floor, wall, b1, b2, b3, lamp] if not boxes_last else [floor, wall, lamp, b1, b2, b3]
+        sb.set_world(sb.list(objs))
+        sb.set_lights(lamp)
+    hosts = {}
+    for boxes_last in (True, False):
+        host, osb = ra.SceneBuilder(), orc.scene()
+        build(host, boxes_last), build(osb, boxes_last)
+        hosts[boxes_last] = (host, osb)
+    cam = ra.CameraSettings(image_width=64, image_height=64, samples_per_px=16, max_depth=8, vfov=60.0, background=(0.0, 0.0, 0.0),
+                            camera_center=(0.5, 4.0, 9.0), camera_target=(0.0, 1.5, 0.0))
+    res = {}
+    for boxes_last, (host, osb) in hosts.items():
+        device.upload(host)
+        info = device.accel_info()
+        assert info["kind"] == "flat" and info["flat_boxes"] == (3 if boxes_last else 0)
+        assert info["flat_quads"] == (3 if boxes_last else 21)
+        o, d, tm, frm = helpers.ray_batch(osb, cam, 32768, seed=5, bbox=((-6, 0, -6), (6, 8, 6)))
+        # rays born inside the first two boxes and on the floor under them
+        rng = np.random.default_rng(2)
+        extra_o = np.concatenate([rng.random((2000, 3)) * (1.2, 2.5, 1.2) + (-3.0, 0.1, -0.3),
+                                  rng.random((2000, 3)) * (0.8, 1.2, 0.8) + (1.6, 0.1, 0.4)]).astype(np.float32)
+        extra_d = rng.standard_normal((4000, 3)).astype(np.float32)
+        o, d = np.concatenate([o, extra_o]), np.concatenate([d, extra_d])
+        tm, frm = np.concatenate([tm, np.zeros(4000, np.float32)]), np.concatenate([frm, -np.ones(4000, np.int32)])
+        hit, prim, t, _, _ = device.intersect_batch(o, d, tm, origin_prim=frm)
+        h2, p2, t2, _, _, second = orc.intersect_batch(osb, o, d, tm)
+        with np.errstate(invalid="ignore"):
+            tie = np.abs(second - t2) <= 1e-5 * np.abs(t2)
+        bad = ((hit != h2) | (prim != p2)) & ~tie
+        assert bad.mean() < 2e-3, (boxes_last, bad.sum())
+        ok = (hit == 1) & (h2 == 1) & (prim == p2)
+        assert np.quantile(np.abs(t[ok] - t2[ok]) / t2[ok], 0.995) < 1e-5
+        # coincident bottom face and floor: the box, later in the list, is reported
+        down_o = np.array([[-2.4, 1.0, 0.3], [2.0, 0.7, 1.0]], np.float32)
+        down = device.intersect_batch(down_o, np.tile(np.float32([0, -1, 0]), (2, 1)), np.zeros(2, np.float32))
+        want = orc.intersect_batch(osb, down_o, np.tile(np.float32([0, -1, 0]), (2, 1)), np.zeros(2))
+        assert (down[1] == want[1]).all() and (down[0] == 1).all()
+        res[boxes_last] = (o, hit, prim, t)
+    (o1, h1, p1, t1), (o0, h0, p0, t0) = res[True], res[False]
+    # the two list orders number the primitives differently; compare hit flags and distances
+    assert np.array_equal(o1, o0) and (h1 == h0).mean() > 0.999
+    both = (h1 == 1) & (h0 == 1)
+    assert np.quantile(np.abs(t1[both] - t0[both]) / t0[both], 0.999) < 1e-5
+    # and a render through the box path against the oracle, same stream
+    host, osb = hosts[True]
+    device.upload(host)
+    device.film_resize(64, 64)
+    for pipeline in ("lane-bound", "regrouped"):
+        device.film_clear()
+        device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=9, **PIPELINES[pipeline])
+        film, _, _ = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=9)
+        r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
+        assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.05, (pipeline, r)
+
+
 def test_ref_exact_rejects_what_the_reference_cannot_render(device):
     host, osb, cam, mode, _ = scene("c3", device)  # glass sphere, light list
     with pytest.raises(ra.RtError, match="todo"):
