@@ -496,8 +496,8 @@ extern "C" {
 #ifdef RT_REGROUP_STATS
 // instrumented builds only: turns and lanes per step of k_paths_regroup since the last call
 int rt_debug_regroup_stats(unsigned long long *out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rg_stats), sizeof(unsigned long long) * 2 * RG_LISTS) != hipSuccess) return -1;
-    unsigned long long zero[2 * RG_LISTS] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rg_stats), sizeof(unsigned long long) * 3 * RG_LISTS) != hipSuccess) return -1;
+    unsigned long long zero[3 * RG_LISTS] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif

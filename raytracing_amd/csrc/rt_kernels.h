@@ -1453,7 +1453,7 @@ static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE, "slot numbers are b
 #define RT_REGROUP_WAVES 4
 #endif
 #ifdef RT_REGROUP_STATS
-__device__ unsigned long long g_rg_stats[2 * RG_LISTS]; // turns and lanes per step (instrumented builds)
+__device__ unsigned long long g_rg_stats[3 * RG_LISTS]; // turns, lanes and clock ticks per step (instrumented builds)
 #define RT_RG_COUNT(stage, m) (rg_turns[stage] += 1, rg_lanes[stage] += (m))
 #else
 #define RT_RG_COUNT(stage, m) ((void)0)
@@ -1477,7 +1477,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     unsigned long long n_seg = 0, n_cam = 0;
     bool exhausted = false;
 #ifdef RT_REGROUP_STATS
-    unsigned long long rg_turns[RG_LISTS] = {}, rg_lanes[RG_LISTS] = {};
+    unsigned long long rg_turns[RG_LISTS] = {}, rg_lanes[RG_LISTS] = {}, rg_ticks[RG_LISTS] = {};
 #endif
     // appends the slots of the lanes where `yes` holds to list `which`
     auto push = [&](uint32_t which, uint32_t &n, bool yes, uint32_t slot) {
@@ -1544,6 +1544,10 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         offer(RG_END, n_end);
         if (!exhausted) offer(RG_FREE, n_free);
         if (most == 0) break;
+#ifdef RT_REGROUP_STATS
+        const unsigned long long rg_t0 = wall_clock64();
+        const uint32_t rg_stage = stage;
+#endif
 
         if (stage == RG_FREE) {
             // slots that hold no path yet (the start of the frame)
@@ -1642,12 +1646,16 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
             else if (stage == RG_GLASS) scatter_turn(std::integral_constant<uint32_t, RT_MAT_DIELECTRIC>{}, n_glass);
             else scatter_turn(std::integral_constant<uint32_t, RT_MAT_METAL>{}, n_metal);
         }
+#ifdef RT_REGROUP_STATS
+        rg_ticks[rg_stage] += wall_clock64() - rg_t0;
+#endif
     }
     if (lane == 0) {
         atomicAdd(&ctrl->segments, n_seg);
         atomicAdd(&ctrl->camera_rays, n_cam);
 #ifdef RT_REGROUP_STATS
-        for (uint32_t i = 0; i < RG_LISTS; ++i) atomicAdd(&g_rg_stats[i], rg_turns[i]), atomicAdd(&g_rg_stats[RG_LISTS + i], rg_lanes[i]);
+        for (uint32_t i = 0; i < RG_LISTS; ++i)
+            atomicAdd(&g_rg_stats[i], rg_turns[i]), atomicAdd(&g_rg_stats[RG_LISTS + i], rg_lanes[i]), atomicAdd(&g_rg_stats[2 * RG_LISTS + i], rg_ticks[i]);
 #endif
     }
 }
