@@ -42,11 +42,18 @@ bin/host_sanitize: $(SAN_SRC) raytracing_amd/host/raytracing.hpp raytracing_amd/
 	g++ -O1 -g $(CXXSTD) -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer \
 	    -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -o $@ $(SAN_SRC) -lz
 
+# the same library with per-step counters in the regrouping kernel (tools/regroup_steps.py)
+STATS_LIB = raytracing_amd/librt_amd_stats.so
+stats-lib: $(STATS_LIB)
+$(STATS_LIB): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h include/rt_amd.h $(HOST_OBJ)
+	$(HIPCC) $(HIPFLAGS) -DRT_REGROUP_STATS -c $< -o raytracing_amd/csrc/rt_device_stats.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ raytracing_amd/csrc/rt_device_stats.o $(HOST_OBJ) -lz
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIB) $(DEV_OBJ) $(HOST_OBJ) $(MAIN) raytracing_amd/host/main.o bin/host_sanitize
+	rm -f $(LIB) $(STATS_LIB) raytracing_amd/csrc/rt_device_stats.o $(DEV_OBJ) $(HOST_OBJ) $(MAIN) raytracing_amd/host/main.o bin/host_sanitize
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean sanitize
+.PHONY: all oracle clean sanitize stats-lib

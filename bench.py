@@ -56,9 +56,11 @@ FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path dep
 # the full workloads; used when the CPU leg is skipped, recomputed when it runs
 FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0}
 # HBM-side bytes per segment of the persistent kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
-# WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments;
-# profiles/r1g_pmc_c3_spp64_persistent.txt).  Not collected live: counters need their own runs.
-PMC_BYTES_PER_SEGMENT = {"c3": (2 * 12796 + 4905618) * 1024 / 861.4e6}
+# WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments), keyed by
+# (workload, regrouping variant): profiles/r1h_pmc_c3_spp64_regroup.txt and
+# profiles/r1g_pmc_c3_spp64_persistent.txt.  Not collected live: counters need their own runs.
+PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 488 + 4113136) * 1024 / 861.4e6,
+                         ("c3", False): (2 * 12796 + 4905618) * 1024 / 861.4e6}
 
 
 def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads):
@@ -198,7 +200,7 @@ def main():
         "kernel_ms_per_step": {n: round(float(per_launch_ms[i] * launches[i]) / args.steps, 3) for i, n in enumerate(names)},
     }
     # ray-queue / film traffic of the dominant kernel against HBM (the secondary roofline)
-    hbm = {"bound": "hbm", "kernel": "k_" + names[k], "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+    hbm = {"bound": "hbm", "kernel": "k_paths_regroup" if (names[k] == "paths" and regrouped) else "k_" + names[k], "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
            "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": int(seg_per_launch),
            "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]), "timed_launches": int(timed[k])}
@@ -226,8 +228,8 @@ def main():
             tflops = fps * seg / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
         out["roofline"] = {"bound": "valu", "kernel": kernel_name, "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 5),
-                           "traffic": (round(PMC_BYTES_PER_SEGMENT[args.workload] * seg_per_launch)
-                                       if names[k] == "paths" and args.workload in PMC_BYTES_PER_SEGMENT and not args.spp else None),
+                           "traffic": (round(PMC_BYTES_PER_SEGMENT[(args.workload, regrouped)] * seg_per_launch)
+                                       if names[k] == "paths" and (args.workload, regrouped) in PMC_BYTES_PER_SEGMENT and not args.spp else None),
                            "traffic_unit": "bytes per launch, HBM side, PMC bytes/segment x segments of this launch",
                            "flops_per_segment": round(fps, 1), "segments_per_launch": int(seg_per_launch),
                            "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]),
