@@ -597,6 +597,47 @@ def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device
         assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.05, (pipeline, r)
 
 
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
+def test_flat_world_with_every_material_and_a_medium(device, pipeline):
+    """One list holding all five materials, a moving sphere, a smoke-filled sphere and a box, lit by
+    a quad and a sphere light in a light list: every kind of step the regrouping kernel sorts
+    paths by (diffuse incl. isotropic, metal, glass, end) and the medium's keyed draw, same
+    stream against the oracle, through every pipeline."""
+    def build(sb):
+        white = sb.lambertian(sb.tex_checker(0.9, sb.tex_solid(0.8, 0.8, 0.8), sb.tex_solid(0.3, 0.5, 0.3)))
+        # (surfaces stay off the checker's cell borders: a floor at y = 0 would take its colour from
+        # the sign of the hit point's rounding error, in the reference as much as here)
+        objs = [sb.quad((-5, -0.25, -5), (10, 0, 0), (0, 0, 10), white),
+                sb.quad((-5, -0.25, -5), (10, 0, 0), (0, 6, 0), sb.lambertian(sb.tex_solid(0.7, 0.3, 0.3))),
+                sb.sphere((-2.5, 1.0, 0.5), 1.0, sb.metal((0.8, 0.8, 0.9), 0.15)),
+                sb.sphere((0.0, 1.0, 1.5), 1.0, sb.dielectric(1.5)),
+                sb.sphere((2.5, 0.8, 0.0), 0.8, sb.lambertian(sb.tex_solid(0.2, 0.3, 0.8)), center_vec=(0.0, 0.4, 0.0)),
+                sb.medium(sb.sphere((0.5, 1.2, -2.0), 1.2, white), 0.6, (0.9, 0.9, 0.9))]
+        lamp = sb.quad((-1.5, 5.9, -1.5), (3, 0, 0), (0, 0, 3), sb.light(sb.tex_solid(6, 6, 6)))
+        bulb = sb.sphere((3.5, 3.5, 2.0), 0.4, sb.light(sb.tex_solid(12, 10, 8)))
+        box = sb.translate(sb.rotate_y(sb.box3((0, 0, 0), (1, 2, 1), white), 30.0), (-4.0, -0.25, 2.0))
+        sb.set_world(sb.list(objs + [lamp, bulb, box]))
+        sb.set_lights(sb.list([lamp, bulb]))
+    host, osb = ra.SceneBuilder(), orc.scene()
+    build(host), build(osb)
+    cam = ra.CameraSettings(image_width=72, image_height=56, samples_per_px=16, max_depth=12, vfov=55.0, background=(0.02, 0.02, 0.04),
+                            camera_center=(0.0, 3.0, 9.0), camera_target=(0.0, 1.2, 0.0))
+    device.upload(host)
+    info = device.accel_info()
+    assert info["kind"] == "flat" and info["flat_boxes"] == 1
+    device.film_resize(72, 56)
+    st = device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=5, **PIPELINES[pipeline])
+    gpu = device.film(1.0 / 16)
+    film, _, cnt = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=5)
+    r = helpers.compare_same_stream(gpu, film / 16)
+    assert np.isfinite(gpu).all() and gpu.max() > 0.1
+    assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.08, r
+    assert np.allclose(r["mean_gpu"], r["mean_cpu"], rtol=0.03), r
+    assert st.camera_rays == cnt["camera_rays"]
+    want = cnt["segments"] - cnt["zero_weight_segments"]
+    assert abs(st.segments - want) <= 1e-2 * want + 5, (st.segments, want)
+
+
 def test_ref_exact_rejects_what_the_reference_cannot_render(device):
     host, osb, cam, mode, _ = scene("c3", device)  # glass sphere, light list
     with pytest.raises(ra.RtError, match="todo"):
