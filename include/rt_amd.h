@@ -238,6 +238,9 @@ typedef struct {
     uint32_t flat_quads;    /* flat only: quads tested one by one */
     uint32_t flat_boxes;    /* flat only: runs of six quads at the end of the list that are the faces of one
                              * rectangular box (box3, hittable.rs:398-455) and take one slab test each */
+    uint32_t flat_alone_spheres; /* flat only: spheres that no other primitive of the list reaches into; the
+                             * regrouping kernel knows where a ray going into one of them ends */
+    uint32_t pad;
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 /* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it

@@ -282,7 +282,7 @@ class Device:
         a = _ffi.RtAccelInfo()
         self._check(self.lib.rt_get_accel_info(self.h, C.byref(a)), "rt_get_accel_info")
         return dict(kind=("flat", "bvh2", "bvh4")[a.kind], nodes=a.nodes, depth=a.depth, stack_entries=a.stack_entries, cost=a.cost,
-                    flat_quads=a.flat_quads, flat_boxes=a.flat_boxes)
+                    flat_quads=a.flat_quads, flat_boxes=a.flat_boxes, flat_alone_spheres=a.flat_alone_spheres)
 
     def upload(self, scene: SceneBuilder):
         desc = scene.flatten()

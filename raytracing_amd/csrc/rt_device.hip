@@ -41,7 +41,7 @@ struct rt_handle {
     uint32_t lds_nodes4 = 0;                // wide nodes staged in LDS behind the stack
     size_t dyn_lds4() const { return size_t(stack4) * BLOCK * sizeof(uint32_t) + size_t(lds_nodes4) * sizeof(Node4); }
     accel::Stats accel_stats{};
-    uint32_t has_media = 0, n_prims = 0;
+    uint32_t has_media = 0, n_prims = 0, alone_spheres = 0;
     bool has_specular = false;
     uint32_t n_textures = 0;
     std::vector<uint32_t> prim_to_ref; // user-visible primitive id -> ref (parity hook)
@@ -371,6 +371,52 @@ bool match_box(const rt_quad *const q[6], const uint32_t refs[6], float rec[32])
     return true;
 }
 
+// A sphere of a flat world that nothing else reaches into: every other primitive of the list
+// keeps at least the radius away from its centre (a rectangle by its true distance, other quads
+// by their plane's, spheres by centre distance; any medium or motion in the list says no).  A
+// ray that leaves such a sphere inwards meets the same sphere next, whatever else the list
+// holds.  Touching counts as away: the ball's interior is open.
+bool sphere_is_alone(const rt_scene_desc *s, const std::vector<uint32_t> &list, uint32_t self) {
+    const rt_sphere &me = s->spheres[self & RT_REF_INDEX_MASK];
+    if (me.moving || me.cv[0] != 0.f || me.cv[1] != 0.f || me.cv[2] != 0.f) return false;
+    const double c[3] = {me.c0[0], me.c0[1], me.c0[2]}, r = me.radius;
+    if (!(r > 0)) return false;
+    for (uint32_t ref : list) {
+        if (ref == self) continue;
+        const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+        double dist = 0;
+        if (kind == RT_KIND_QUAD) {
+            const rt_quad &q = s->quads[idx];
+            double rel[3], uu = 0, vv = 0, uv = 0, ru = 0, rv = 0, rn = 0;
+            for (int a = 0; a < 3; ++a) {
+                rel[a] = c[a] - q.q[a];
+                uu += double(q.u[a]) * q.u[a], vv += double(q.v[a]) * q.v[a], uv += double(q.u[a]) * q.v[a];
+                ru += rel[a] * q.u[a], rv += rel[a] * q.v[a], rn += rel[a] * q.n[a];
+            }
+            dist = std::fabs(rn); // the plane's distance bounds any shape's from below
+            if (q.shape == RT_SHAPE_PARALLELOGRAM && uu > 0 && vv > 0 && std::fabs(uv) <= 1e-9 * std::sqrt(uu * vv)) {
+                const double a = std::min(1.0, std::max(0.0, ru / uu)), b = std::min(1.0, std::max(0.0, rv / vv));
+                double d2 = 0; // a rectangle: clamping the coordinates gives its closest point
+                for (int k = 0; k < 3; ++k) {
+                    const double e = rel[k] - a * q.u[k] - b * q.v[k];
+                    d2 += e * e;
+                }
+                dist = std::sqrt(d2);
+            }
+        } else if (kind == RT_KIND_SPHERE) {
+            const rt_sphere &o = s->spheres[idx];
+            if (o.moving || o.cv[0] != 0.f || o.cv[1] != 0.f || o.cv[2] != 0.f) return false;
+            double d2 = 0;
+            for (int a = 0; a < 3; ++a) d2 += (c[a] - o.c0[a]) * (c[a] - o.c0[a]);
+            dist = std::sqrt(d2) - o.radius;
+        } else {
+            return false;
+        }
+        if (!(dist >= r)) return false;
+    }
+    return true;
+}
+
 // timed launch helper
 struct Timer {
     rt_handle *h;
@@ -617,6 +663,9 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     // list order for scalar loads, everything else by reference.
     std::vector<float> flat_quads, flat_boxes;
     std::vector<uint32_t> flat_other, flat_quad_refs;
+    // device copy of the spheres: pad = 1 marks a sphere of a flat world that nothing reaches into
+    std::vector<rt_sphere> spheres(s->spheres, s->spheres + s->n_spheres);
+    for (rt_sphere &sp : spheres) sp.pad = 0;
     h->flat = false;
     {
         uint32_t rk = s->root >> RT_REF_KIND_SHIFT, ri = s->root & RT_REF_INDEX_MASK;
@@ -656,6 +705,9 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
                     flat_quads.resize(first * 16);
                 }
                 flat_boxes = found;
+                const std::vector<uint32_t> list(s->refs + s->nodes[ri].left, s->refs + s->nodes[ri].left + s->nodes[ri].count);
+                for (uint32_t r : list)
+                    if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE && sphere_is_alone(s, list, r)) spheres[r & RT_REF_INDEX_MASK].pad = 1;
             }
         }
     }
@@ -723,7 +775,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.n_flat_other = uint32_t(flat_other.size());
     d.n_flat_boxes = uint32_t(flat_boxes.size() / 32);
     if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
-        upload(h, s->quads, s->n_quads, &dq) || upload(h, s->spheres, s->n_spheres, &ds) ||
+        upload(h, s->quads, s->n_quads, &dq) || upload(h, spheres.data(), spheres.size(), &ds) ||
         upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || upload(h, nodes4.data(), nodes4.size(), &dn4) ||
         upload(h, flat_other.data(), flat_other.size(), &d.flat_other) ||
         upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
@@ -746,6 +798,8 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     h->sc = d;
     h->have_scene = true;
     h->has_media = s->n_media ? 1u : 0u;
+    h->alone_spheres = 0;
+    for (const rt_sphere &sp : spheres) h->alone_spheres += sp.pad;
     h->n_prims = s->n_prims;
     h->n_textures = s->n_textures;
     h->has_specular = false;
@@ -789,7 +843,7 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
     if (out) {
         out->kind = uint32_t(ACCEL_BVH4);
         out->nodes = st.nodes, out->depth = st.depth, out->stack_entries = st.stack_need, out->cost = st.cost;
-        out->flat_quads = out->flat_boxes = 0;
+        out->flat_quads = out->flat_boxes = out->flat_alone_spheres = out->pad = 0;
     }
     return 0;
 }
@@ -804,6 +858,8 @@ int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     out->cost = h->accel == ACCEL_BVH4 ? h->accel_stats.cost : 0.0;
     out->flat_quads = h->accel == ACCEL_FLAT ? h->sc.n_flat_quads : 0u;
     out->flat_boxes = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes : 0u;
+    out->flat_alone_spheres = h->alone_spheres;
+    out->pad = 0;
     return 0;
 }
 

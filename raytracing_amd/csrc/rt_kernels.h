@@ -1619,7 +1619,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 n_list -= m;
                 const bool active = lane < m;
                 uint32_t slot = 0;
-                bool alive = false;
+                bool alive = false, again = false; // again: the next hit is known and is a vertex of this kind
                 if (active) {
                     slot = pool.list[stage][n_list + lane];
                     float4 ra = pool.ra[slot], rb = pool.rb[slot], sa = pool.sa[slot];
@@ -1630,6 +1630,23 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                     Rng rng;
                     rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
                     alive = shade_scatter<MODE, ONLY>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+                    if (ONLY == RT_MAT_DIELECTRIC && alive && (sf.ref >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE) {
+                        // A ray going into a sphere that nothing else reaches into (marked at
+                        // upload) meets that sphere next: the closest-hit query is answered here,
+                        // with the root the scan's own sphere test takes for a ray that starts on
+                        // the sphere, and the path stays with the glass vertices.
+                        const float4 *S = sc.spheres + 3 * (sf.ref & RT_REF_INDEX_MASK);
+                        const V3 dir = mk(rb);
+                        if (fbits(S[2].w) != 0u && (dot(dir, sf.n) < 0.0f) == sf.front) {
+                            const SphereEq q = sphere_eq(S[0], S[1], mk(ra), dir, ra.w);
+                            const float root = 2.0f * q.h * q.inv_a;
+                            if (0.001f < root && root < RT_INF && !(q.disc < 0.0f)) {
+                                const V3 hp = fma3(dir, root, mk(ra));
+                                ra = make_float4(hp.x, hp.y, hp.z, ra.w);
+                                again = true;
+                            }
+                        }
+                    }
                     if (alive) {
                         pool.ra[slot] = ra;
                         pool.rb[slot] = rb;
@@ -1639,7 +1656,11 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                         pool.rb[slot].w = bitsf(RG_REF_NOTHING);
                     }
                 }
-                push(RG_RAY, n_ray, alive, slot);
+                if (ONLY == RT_MAT_DIELECTRIC) {
+                    n_seg += uint32_t(__popcll(__ballot(again)));
+                    push(stage, n_list, again, slot);
+                }
+                push(RG_RAY, n_ray, alive && !again, slot);
                 push(RG_END, n_end, active && !alive, slot);
             };
             if (stage == RG_DIFFUSE) scatter_turn(std::integral_constant<uint32_t, RT_MAT_LAMBERTIAN>{}, n_diffuse);

@@ -638,6 +638,44 @@ def test_flat_world_with_every_material_and_a_medium(device, pipeline):
     assert abs(st.segments - want) <= 1e-2 * want + 5, (st.segments, want)
 
 
+@pytest.mark.parametrize("cut", [False, True], ids=["sphere-alone", "sphere-cut-by-a-quad"])
+def test_glass_sphere_inside_segments(device, cut):
+    """The regrouping kernel answers the closest-hit query of a ray going into a glass sphere
+    itself when nothing else of the list reaches into that sphere (decided at upload).  A sphere
+    resting on the floor (touching counts as apart) takes that shortcut; one with a quad through
+    its middle, and one overlapping another sphere, must not.  Same stream against the oracle,
+    and the two persistent variants agree on the segment count."""
+    def build(sb):
+        grey = sb.lambertian(sb.tex_solid(0.7, 0.7, 0.7))
+        objs = [sb.quad((-4, 0, -4), (8, 0, 0), (0, 0, 8), grey),
+                sb.quad((-4, 0, -4), (8, 0, 0), (0, 6, 0), sb.lambertian(sb.tex_solid(0.3, 0.6, 0.3))),
+                sb.sphere((-1.2, 1.0, 0.0), 1.0, sb.dielectric(1.5)),
+                sb.sphere((1.6, 0.8, 0.5), 0.8, sb.dielectric(1.3))]
+        if cut:
+            objs.append(sb.quad((-2.2, 1.0, -1.0), (2.0, 0, 0), (0, 0.3, 2.0), sb.lambertian(sb.tex_solid(0.8, 0.2, 0.2))))
+            objs.append(sb.sphere((2.2, 0.8, 0.9), 0.5, sb.metal((0.9, 0.9, 0.9), 0.0)))
+        lamp = sb.quad((-1, 5.5, -1), (2, 0, 0), (0, 0, 2), sb.light(sb.tex_solid(10, 10, 10)))
+        sb.set_world(sb.list(objs + [lamp]))
+        sb.set_lights(lamp)
+    host, osb = ra.SceneBuilder(), orc.scene()
+    build(host), build(osb)
+    cam = ra.CameraSettings(image_width=64, image_height=48, samples_per_px=16, max_depth=16, vfov=50.0, background=(0.05, 0.05, 0.08),
+                            camera_center=(0.0, 2.5, 7.0), camera_target=(0.0, 1.0, 0.0))
+    device.upload(host)
+    assert device.accel_info()["flat_alone_spheres"] == (0 if cut else 2)
+    device.film_resize(64, 48)
+    film, _, cnt = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=4)
+    segs = {}
+    for pipeline in ("regrouped", "lane-bound"):
+        device.film_clear()
+        st = device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=4, **PIPELINES[pipeline])
+        r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
+        assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.08, (pipeline, r)
+        segs[pipeline] = st.segments
+    want = cnt["segments"] - cnt["zero_weight_segments"]
+    assert abs(segs["regrouped"] - want) <= 1e-2 * want and abs(segs["regrouped"] - segs["lane-bound"]) <= 2e-3 * want, (segs, want)
+
+
 def test_ref_exact_rejects_what_the_reference_cannot_render(device):
     host, osb, cam, mode, _ = scene("c3", device)  # glass sphere, light list
     with pytest.raises(ra.RtError, match="todo"):
