@@ -507,7 +507,7 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
     int rc;
     // the regrouping kernel packs stratum and bounce into one word
-    const bool regroup_fits = dc.sqrt_spp <= 4096u && dc.max_depth <= REGROUP_MAX_DEPTH;
+    const bool regroup_fits = uint64_t(dc.sqrt_spp) * dc.sqrt_spp <= REGROUP_MAX_STRATA && dc.max_depth <= REGROUP_MAX_DEPTH;
     const bool regroup_wanted = (p->flags & RT_FLAG_REGROUP) || (!(p->flags & RT_FLAG_NO_REGROUP) && p->mode == RT_MODE_BOOK3);
     if (h->accel == ACCEL_FLAT && regroup_wanted && regroup_fits) {
         rc = p->mode == RT_MODE_REF_EXACT ? launch_paths_regroup<RT_MODE_REF_EXACT>(h, p, film, total)

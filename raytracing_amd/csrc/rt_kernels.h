@@ -1438,7 +1438,8 @@ constexpr int REGROUP_SLOTS = RT_REGROUP_SLOTS;
 enum : uint32_t { RG_FREE = 0, RG_RAY = 1, RG_DIFFUSE = 2, RG_METAL = 3, RG_GLASS = 4, RG_END = 5, RG_LISTS = 6 };
 constexpr uint32_t RG_REF_NOTHING = 0xFFFFFFFEu; // in place of a hit's ref: the path ended with nothing to deposit
 // A slot is 52 bytes + 6 list bytes: the pool size sets how full the turns run (measured on the
-// Book-3 Cornell box: 96 slots 34.8, 128 42.0, 144 43.8 G segments/s), and 16 waves share 160 KB.
+// Book-3 Cornell box: 96 slots 34.8, 128 42.0, 144 43.8, 176 45.9 G segments/s), and the 16 waves
+// of a compute unit share 160 KB: 4 x 176 slots is 40 832 bytes a block.
 //   ra: origin and time; once the closest hit is found, the hit point and time
 //   rb: direction and the ref of the primitive the ray leaves; once the hit is found, the hit's ref
 //   sa: throughput and pixel;  sb: stratum | bounce << 24
