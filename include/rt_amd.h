@@ -170,10 +170,11 @@ typedef struct {
 /* Persistent kernel on a flat world (one list of primitives): either every lane carries one path
  * from its camera ray to its end, or every wave keeps a pool of paths in LDS and regroups them
  * by the step they wait for (closest hit, scatter at a diffuse / metal / glass vertex, end), so
- * that each step runs with most lanes active.  Same image either way.  Default: regrouping for
- * RT_MODE_BOOK3 (measured 28 % faster on the Book-3 Cornell box), lane-bound paths for
- * RT_MODE_REF_EXACT (one kind of scatter, paths of about two segments: 2 % faster lane-bound).
- * Regrouping needs sqrt_spp <= 4096 and max_depth <= 255 and falls back otherwise. */
+ * that each step runs with most lanes active.  Same image either way.  Default: regrouping
+ * (measured 40 % faster on the Book-3 Cornell box, 3 % on the main.rs scene, whose paths are
+ * about two segments long and scatter one way).  RT_FLAG_NO_REGROUP takes the lane-bound
+ * kernel; RT_FLAG_REGROUP is the default spelled out.
+ * Regrouping needs max_depth <= 255 and falls back otherwise. */
 #define RT_FLAG_REGROUP 4u
 #define RT_FLAG_NO_REGROUP 8u
 typedef struct {

@@ -41,7 +41,7 @@ struct rt_handle {
     uint32_t lds_nodes4 = 0;                // wide nodes staged in LDS behind the stack
     size_t dyn_lds4() const { return size_t(stack4) * BLOCK * sizeof(uint32_t) + size_t(lds_nodes4) * sizeof(Node4); }
     accel::Stats accel_stats{};
-    uint32_t has_media = 0, n_prims = 0, alone_spheres = 0;
+    uint32_t has_media = 0, n_prims = 0, alone_spheres = 0, n_quads = 0, n_spheres = 0, n_materials = 0;
     bool has_specular = false;
     uint32_t n_textures = 0;
     std::vector<uint32_t> prim_to_ref; // user-visible primitive id -> ref (parity hook)
@@ -479,9 +479,9 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
 }
 
 // The regrouping variant of the persistent kernel (flat worlds): same launch shape.
-template <int MODE>
+template <int MODE, bool TABLES>
 int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &film, unsigned long long total) {
-    auto kernel = k_paths_regroup<MODE>;
+    auto kernel = k_paths_regroup<MODE, TABLES>;
     int per_cu = 0, n_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
@@ -494,7 +494,7 @@ int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &fi
     Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
     int e = tm.begin(4);
     kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), 0, h->stream>>>(h->d_sc, h->d_cam, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
-                                                                 h->d_ctrl, h->has_media, 1024u);
+                                                                 h->d_ctrl, h->has_media, 1024u, h->n_quads, h->n_spheres, h->n_materials);
     tm.end(e);
     RT_HIP(hipGetLastError());
     h->stats.launches[4]++;
@@ -508,10 +508,14 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     int rc;
     // the regrouping kernel packs stratum and bounce into one word
     const bool regroup_fits = uint64_t(dc.sqrt_spp) * dc.sqrt_spp <= REGROUP_MAX_STRATA && dc.max_depth <= REGROUP_MAX_DEPTH;
-    const bool regroup_wanted = (p->flags & RT_FLAG_REGROUP) || (!(p->flags & RT_FLAG_NO_REGROUP) && p->mode == RT_MODE_BOOK3);
+    const bool regroup_wanted = !(p->flags & RT_FLAG_NO_REGROUP);
     if (h->accel == ACCEL_FLAT && regroup_wanted && regroup_fits) {
-        rc = p->mode == RT_MODE_REF_EXACT ? launch_paths_regroup<RT_MODE_REF_EXACT>(h, p, film, total)
-                                          : launch_paths_regroup<RT_MODE_BOOK3>(h, p, film, total);
+        // a small scene's quads, spheres and materials are copied into LDS tables
+        const bool tables = h->n_quads <= TABLE_QUADS && h->n_spheres <= TABLE_SPHERES && h->n_materials <= TABLE_MATERIALS;
+        if (p->mode == RT_MODE_REF_EXACT)
+            rc = tables ? launch_paths_regroup<RT_MODE_REF_EXACT, true>(h, p, film, total) : launch_paths_regroup<RT_MODE_REF_EXACT, false>(h, p, film, total);
+        else
+            rc = tables ? launch_paths_regroup<RT_MODE_BOOK3, true>(h, p, film, total) : launch_paths_regroup<RT_MODE_BOOK3, false>(h, p, film, total);
     } else {
 #define RT_PATHS(MODE)                                                                                    \
     (h->accel == ACCEL_FLAT   ? launch_paths<MODE, ACCEL_FLAT>(h, dc, p, film, total)                        \
@@ -798,6 +802,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     h->sc = d;
     h->have_scene = true;
     h->has_media = s->n_media ? 1u : 0u;
+    h->n_quads = s->n_quads, h->n_spheres = s->n_spheres, h->n_materials = s->n_materials;
     h->alone_spheres = 0;
     for (const rt_sphere &sp : spheres) h->alone_spheres += sp.pad;
     h->n_prims = s->n_prims;

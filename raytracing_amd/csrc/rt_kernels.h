@@ -777,6 +777,16 @@ __device__ __forceinline__ V3 tex_value(SceneRef sc, uint32_t id, float u, float
 }
 
 // ------------------------------------------------------------------ lights (hittable.rs:377-395)
+// Copies in LDS of what shading reads per vertex from a small scene -- a quad's normal and material
+// id, the sphere records, the material records -- made once per block by k_paths_regroup: a
+// vertex then costs two LDS reads instead of two dependent loads from memory (measured on the
+// Book-3 Cornell box: the ray step's material lookup alone was 6.6 % of the frame).
+constexpr uint32_t TABLE_QUADS = 48, TABLE_SPHERES = 8, TABLE_MATERIALS = 16;
+struct FlatTables {
+    const float4 *quad_nm;    // n.xyz, material id (bits)
+    const float4 *spheres;    // as DScene::spheres
+    const rt_material *mats;
+};
 // direction to a random point of light `r`, unnormalised (Parallelogram::random), or towards
 // the visible cap of a sphere
 // UNIFORM: r is the same in every lane, so the light's record comes through scalar loads.
@@ -1047,11 +1057,11 @@ struct Surface {
 // quad_uv_missing: the hit came from the flat scan, which does not carry a quad's (alpha, beta)
 // through its loop; they are recomputed here for the materials that look at them.
 // DEPOSIT = false: the caller knows the hit is a surface that scatters (k_paths_regroup's scatter
-// steps); only `sf` is wanted.
-template <bool DEPOSIT = true>
+// steps); only `sf` is wanted.  TABLES: quads, spheres and materials come from `tb`.
+template <bool DEPOSIT = true, bool TABLES = false>
 __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &film, const float4 &ra,
                                            const float4 &rb, const float4 &sa, float4 h, bool quad_uv_missing,
-                                           Surface &sf) {
+                                           Surface &sf, const FlatTables &tb = FlatTables{}) {
     const V3 o = mk(ra), d = mk(rb), thr = mk(sa);
     const float time = ra.w;
     const uint32_t pixel = fbits(sa.w);
@@ -1074,16 +1084,28 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
         float u = h.z, v = h.w, u_shift = 0.f;
         bool front = true;
         if (kind == RT_KIND_QUAD) {
-            const float4 *Q = sc.quads + 6 * idx;
-            n = mk(Q[1]);
-            mat_id = fbits(Q[3].w);
+            if (TABLES) {
+                const float4 nm = tb.quad_nm[idx];
+                n = mk(nm);
+                mat_id = fbits(nm.w);
+            } else {
+                const float4 *Q = sc.quads + 6 * idx;
+                n = mk(Q[1]);
+                mat_id = fbits(Q[3].w);
+            }
         } else if (kind == RT_KIND_SPHERE) {
-            const float4 *S = sc.spheres + 3 * idx;
-            float4 s0 = S[0], s1 = S[1];
+            float4 s0, s1;
+            if (TABLES) {
+                s0 = tb.spheres[3 * idx], s1 = tb.spheres[3 * idx + 1];
+                u_shift = tb.spheres[3 * idx + 2].z;
+            } else {
+                const float4 *S = sc.spheres + 3 * idx;
+                s0 = S[0], s1 = S[1];
+                u_shift = S[2].z;
+            }
             V3 center = fma3(mk(s1), time, mk(s0));
             n = (p - center) * rcp(s0.w);
             mat_id = fbits(s1.w);
-            u_shift = S[2].z;
         } else { // ConstantMedium: arbitrary normal, front face (hittable.rs:877-885)
             n = {1.f, 0.f, 0.f};
             mat_id = sc.media[idx].mat;
@@ -1092,7 +1114,9 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
             front = dot(d, n) < 0.0f;
             if (!front) n = -n;
         }
-        const rt_material m = sc.mats[mat_id];
+        rt_material m;
+        if (TABLES) m = tb.mats[mat_id];
+        else m = sc.mats[mat_id];
         if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
         if (kind == RT_KIND_QUAD && quad_uv_missing && m.needs_uv) quad_uv(sc.quads + 6 * idx, p, u, v);
         if (DEPOSIT && m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
@@ -1432,14 +1456,15 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
 // Exit: a wave leaves when the sample counter has run out and every list but the free one is
 // empty; each step moves its slots on and a path ends within max_depth bounces.
 #ifndef RT_REGROUP_SLOTS
-#define RT_REGROUP_SLOTS 176
+#define RT_REGROUP_SLOTS 168
 #endif
 constexpr int REGROUP_SLOTS = RT_REGROUP_SLOTS;
 enum : uint32_t { RG_FREE = 0, RG_RAY = 1, RG_DIFFUSE = 2, RG_METAL = 3, RG_GLASS = 4, RG_END = 5, RG_LISTS = 6 };
 constexpr uint32_t RG_REF_NOTHING = 0xFFFFFFFEu; // in place of a hit's ref: the path ended with nothing to deposit
 // A slot is 52 bytes + 6 list bytes: the pool size sets how full the turns run (measured on the
 // Book-3 Cornell box: 96 slots 34.8, 128 42.0, 144 43.8, 176 45.9 G segments/s), and the 16 waves
-// of a compute unit share 160 KB: 4 x 176 slots is 40 832 bytes a block.
+// of a compute unit share 160 KB: 4 x 168 slots is 38 976 bytes a block, the scene tables
+// (FlatTables) take 1 664 more.
 //   ra: origin and time; once the closest hit is found, the hit point and time
 //   rb: direction and the ref of the primitive the ray leaves; once the hit is found, the hit's ref
 //   sa: throughput and pixel;  sb: stratum | bounce << 24
@@ -1460,12 +1485,26 @@ __device__ unsigned long long g_rg_stats[3 * RG_LISTS]; // turns, lanes and cloc
 #define RT_RG_COUNT(stage, m) ((void)0)
 #endif
 
-template <int MODE>
+// TABLES: the scene is small enough for FlatTables (the launch checks the counts).
+template <int MODE, bool TABLES>
 __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const DScene *scp, const DCamera *camp, Film film, uint32_t k0,
-                                                          uint32_t k1, Ctrl *ctrl, uint32_t has_media, uint32_t grab) {
+                                                          uint32_t k1, Ctrl *ctrl, uint32_t has_media, uint32_t grab,
+                                                          uint32_t n_quads, uint32_t n_spheres, uint32_t n_mats) {
     SceneRef sc = *as_uniform(scp);
     CamRef cam = *as_uniform(camp);
     __shared__ RegroupPool s_pool[BLOCK / WAVE];
+    __shared__ float4 s_quad_nm[TABLES ? TABLE_QUADS : 1], s_spheres[TABLES ? 3 * TABLE_SPHERES : 1];
+    __shared__ rt_material s_mats[TABLES ? TABLE_MATERIALS : 1];
+    if (TABLES) { // the only barrier of the kernel: before any wave takes its first turn
+        for (uint32_t i = threadIdx.x; i < n_quads; i += BLOCK) {
+            const float4 q1 = sc.quads[6 * i + 1];
+            s_quad_nm[i] = make_float4(q1.x, q1.y, q1.z, sc.quads[6 * i + 3].w);
+        }
+        for (uint32_t i = threadIdx.x; i < 3 * n_spheres; i += BLOCK) s_spheres[i] = sc.spheres[i];
+        for (uint32_t i = threadIdx.x; i < n_mats; i += BLOCK) s_mats[i] = sc.mats[i];
+        __syncthreads();
+    }
+    const FlatTables tb{s_quad_nm, s_spheres, s_mats};
     RegroupPool &pool = s_pool[threadIdx.x / WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     for (uint32_t i = lane; i < uint32_t(REGROUP_SLOTS); i += WAVE) pool.list[RG_FREE][i] = uint8_t(i);
@@ -1569,7 +1608,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 const float4 rb = pool.rb[slot];
                 if (fbits(rb.w) != RG_REF_NOTHING) {
                     Surface sf; // ra holds the hit point: t = 0 from there
-                    (void)shade_emit(sc, cam, film, pool.ra[slot], rb, pool.sa[slot], make_float4(0.f, rb.w, 0.f, 0.f), true, sf);
+                    (void)shade_emit<true, TABLES>(sc, cam, film, pool.ra[slot], rb, pool.sa[slot], make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
                 }
             }
             const uint32_t taken = new_paths(m, slot);
@@ -1596,10 +1635,14 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 uint32_t type = RT_MAT_LIGHT;
                 if (best.ref != RT_REF_NONE) {
                     const uint32_t pk = best.ref >> RT_REF_KIND_SHIFT, idx = best.ref & RT_REF_INDEX_MASK;
-                    const uint32_t mat_id = pk == RT_KIND_QUAD     ? fbits(sc.quads[6 * idx + 3].w)
-                                            : pk == RT_KIND_SPHERE ? fbits(sc.spheres[3 * idx + 1].w)
-                                                                   : sc.media[idx].mat;
-                    type = sc.mats[mat_id].type;
+                    uint32_t mat_id;
+                    if (TABLES) {
+                        mat_id = pk == RT_KIND_QUAD ? fbits(s_quad_nm[idx].w) : pk == RT_KIND_SPHERE ? fbits(s_spheres[3 * idx + 1].w) : sc.media[idx].mat;
+                        type = s_mats[mat_id].type;
+                    } else {
+                        mat_id = pk == RT_KIND_QUAD ? fbits(sc.quads[6 * idx + 3].w) : pk == RT_KIND_SPHERE ? fbits(sc.spheres[3 * idx + 1].w) : sc.media[idx].mat;
+                        type = sc.mats[mat_id].type;
+                    }
                 }
                 const V3 p = fma3(mk(rb), best.t, mk(ra)); // as shade_emit forms it
                 pool.ra[slot] = make_float4(p.x, p.y, p.z, ra.w);
@@ -1627,7 +1670,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                     const uint32_t packed = pool.sb[slot];
                     uint2 sb = make_uint2(packed & 0xFFFFFFu, packed >> 24);
                     Surface sf; // ra holds the hit point: t = 0 from there
-                    (void)shade_emit<false>(sc, cam, film, ra, rb, sa, make_float4(0.f, rb.w, 0.f, 0.f), true, sf);
+                    (void)shade_emit<false, TABLES>(sc, cam, film, ra, rb, sa, make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
                     Rng rng;
                     rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
                     alive = shade_scatter<MODE, ONLY>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
@@ -1636,7 +1679,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                         // upload) meets that sphere next: the closest-hit query is answered here,
                         // with the root the scan's own sphere test takes for a ray that starts on
                         // the sphere, and the path stays with the glass vertices.
-                        const float4 *S = sc.spheres + 3 * (sf.ref & RT_REF_INDEX_MASK);
+                        const float4 *S = (TABLES ? s_spheres : sc.spheres) + 3 * (sf.ref & RT_REF_INDEX_MASK);
                         const V3 dir = mk(rb);
                         if (fbits(S[2].w) != 0u && (dot(dir, sf.n) < 0.0f) == sf.front) {
                             const SphereEq q = sphere_eq(S[0], S[1], mk(ra), dir, ra.w);

@@ -251,8 +251,8 @@ def test_render_same_stream_pixelwise(device, name, med, frac, pipeline):
     st = device.render(rc, mode=mode, seed=1, **PIPELINES[pipeline])
     if pipeline in ("lane-bound", "regrouped"):
         assert st.regrouped == (pipeline == "regrouped")
-    if pipeline == "persistent":  # the library's choice: regrouping on a flat world under the mixture estimator
-        assert st.regrouped == (name in FLAT_WORLDS and mode == ra.RT_MODE_BOOK3)
+    if pipeline == "persistent":  # the library's choice: regrouping on a flat world
+        assert st.regrouped == (name in FLAT_WORLDS)
     gpu = device.film(1.0 / cam.effective_spp)
     film, _, cnt = orc.render(osb, cam, mode=mode, seed=1)
     cpu = film / cam.effective_spp
@@ -674,6 +674,38 @@ def test_glass_sphere_inside_segments(device, cut):
         segs[pipeline] = st.segments
     want = cnt["segments"] - cnt["zero_weight_segments"]
     assert abs(segs["regrouped"] - want) <= 1e-2 * want and abs(segs["regrouped"] - segs["lane-bound"]) <= 2e-3 * want, (segs, want)
+
+
+def test_flat_world_too_large_for_the_scene_tables(device):
+    """The regrouping kernel keeps a small scene's quads, spheres and materials in LDS tables
+    (48 quads, 8 spheres, 16 materials); a list beyond that is rendered from memory.  55 tiles,
+    each with a material of its own, a box and a lamp: same stream against the oracle."""
+    def build(sb):
+        rng = np.random.default_rng(1)
+        objs = []
+        for i in range(11):
+            for j in range(5):
+                mat = sb.lambertian(sb.tex_solid(*(0.2 + 0.7 * rng.random(3))))
+                objs.append(sb.quad((-5.5 + i, 0.0, -2.5 + j), (1, 0, 0), (0, 0, 1), mat))
+        lamp = sb.quad((-2, 3.0, -1), (4, 0, 0), (0, 0, 2), sb.light(sb.tex_solid(5, 5, 5)))
+        box = sb.translate(sb.box3((0, 0, 0), (1, 1, 1), sb.metal((0.9, 0.8, 0.7), 0.1)), (-0.5, 0.0, -0.5))
+        sb.set_world(sb.list(objs + [lamp, box]))
+        sb.set_lights(lamp)
+    host, osb = ra.SceneBuilder(), orc.scene()
+    build(host), build(osb)
+    cam = ra.CameraSettings(image_width=64, image_height=40, samples_per_px=16, max_depth=8, vfov=60.0, background=(0.1, 0.1, 0.1),
+                            camera_center=(0.0, 2.5, 6.0), camera_target=(0.0, 0.5, 0.0))
+    device.upload(host)
+    info = device.accel_info()
+    assert info["kind"] == "flat" and info["flat_quads"] == 56 and info["flat_boxes"] == 1
+    device.film_resize(64, 40)
+    film, _, cnt = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=6)
+    for pipeline in ("regrouped", "lane-bound"):
+        device.film_clear()
+        st = device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=6, **PIPELINES[pipeline])
+        r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
+        assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.06, (pipeline, r)
+        assert st.camera_rays == cnt["camera_rays"]
 
 
 def test_ref_exact_rejects_what_the_reference_cannot_render(device):
