@@ -59,7 +59,7 @@ FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0}
 # WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments), keyed by
 # (workload, regrouping variant): profiles/r1h_pmc_c3_spp64_regroup.txt and
 # profiles/r1g_pmc_c3_spp64_persistent.txt.  Not collected live: counters need their own runs.
-PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 493 + 4091460) * 1024 / 861.4e6,
+PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 510 + 4073925) * 1024 / 861.4e6,
                          ("c3", False): (2 * 12796 + 4905618) * 1024 / 861.4e6}
 
 
