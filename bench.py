@@ -28,6 +28,8 @@ import torch.distributed as dist
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# Importing the package loads the HIP library but makes no HIP call: a process that goes on to
+# start the ranks of a multi-GPU run (below) has not touched the GPU when it does.
 import raytracing_amd as ra  # noqa: E402
 from raytracing_amd import distributed as rdist  # noqa: E402
 
@@ -106,11 +108,27 @@ def main():
                     help="rehearsal on a one-GPU machine: every rank uses GPU 0 (needs --backend gloo); the line is marked")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.share_gpu and (args.backend or "gloo") != "gloo":
+        raise SystemExit("--share-gpu needs --backend gloo: RCCL refuses two ranks on one GPU")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: this process becomes the launcher.  It has made no
+        # HIP or torch.cuda call (device_count() does not initialise the GPU); the N ranks are fresh
+        # processes, rank 0 prints the JSON line to the inherited stdout, this one only waits.
+        have = torch.cuda.device_count()
+        if have < 1:
+            raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+        if have < args.gpus and not args.share_gpu:
+            raise SystemExit(f"--gpus {args.gpus} but only {have} GPU(s) are visible (use --share-gpu --backend gloo to rehearse on one)")
+        raise SystemExit(rdist.spawn_ranks([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], args.gpus,
+                                           share_gpu=args.share_gpu))
     if args.share_gpu:
         os.environ["LOCAL_RANK"] = "0"
+        args.backend = "gloo"
     rank, world, local = rdist.init_from_env(args.backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
@@ -161,7 +179,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    stats = torch.tensor([elapsed, float(seg), float(cam_rays)], dtype=torch.float64, device="cuda")
+    on_host = world > 1 and dist.get_backend() == "gloo"
+    stats = torch.tensor([elapsed, float(seg), float(cam_rays)], dtype=torch.float64, device="cpu" if on_host else "cuda")
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

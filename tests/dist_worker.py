@@ -1,0 +1,42 @@
+"""One rank of the multi-rank GPU test (started by tests/test_gpu_distributed.py through
+spawn_ranks): renders its share of the strata of a few consecutive frames through
+DistributedRenderer, all ranks on GPU 0 with the gloo backend, and saves every reduced film."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main(out_dir, scene, width, spp, seeds):
+    import torch
+    import torch.distributed as dist
+    import raytracing_amd as ra
+    from raytracing_amd import distributed as rdist
+
+    rank, world, local = rdist.init_from_env(backend="gloo")
+    assert local == 0
+    torch.cuda.set_device(0)
+    sb = ra.SceneBuilder()
+    cam = getattr(ra.scenes, scene)(sb, width=width, spp=spp)
+    dev = ra.Device(0)
+    dev.upload(sb)
+    renderer = rdist.DistributedRenderer(dev, 0)
+    rcam = cam.build()
+    mode = ra.RT_MODE_REF_EXACT if scene == "cornell_main" else ra.RT_MODE_BOOK3
+    for seed in seeds:  # consecutive frames into the same film: clear, render and reduce must stay ordered
+        film, st = renderer.render(rcam, cam.effective_spp, rank, world, mode, seed=seed)
+        seg = torch.tensor([float(st.segments if st else 0), float(st.camera_rays if st else 0)], dtype=torch.float64)
+        dist.all_reduce(seg)
+        np.save(Path(out_dir) / f"film_r{rank}_s{seed}.npy", film.cpu().numpy())
+        if rank == 0:
+            np.save(Path(out_dir) / f"seg_s{seed}.npy", seg.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+    dev.close()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), [int(s) for s in sys.argv[5].split(",")])

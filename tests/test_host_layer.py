@@ -659,14 +659,47 @@ def test_host_layer_is_clean_under_sanitizers_and_fuzzing(tmp_path):
 
 def test_bench_refuses_to_run_without_a_device_or_with_a_wrong_world_size():
     """bench.py measures the HIP path only: without a GPU it stops with a message instead of
-    timing anything else, and --gpus must match the launcher's WORLD_SIZE."""
+    timing anything else -- also when asked to start several ranks itself -- and under a launcher
+    --gpus must match WORLD_SIZE."""
     import os
     import subprocess
     import sys
     import torch
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    bench = [sys.executable, str(ROOT / "bench.py")]
+    r = subprocess.run(bench + ["--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and '"metric"' not in r.stdout
+    r = subprocess.run(bench + ["--gpus", "2", "--share-gpu", "--backend", "nccl"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "--share-gpu needs --backend gloo" in r.stderr
     if not torch.cuda.is_available():
-        r = subprocess.run([sys.executable, str(ROOT / "bench.py")], capture_output=True, text=True, timeout=300, env=env)
-        assert r.returncode != 0 and "needs a GPU" in r.stderr and '"metric"' not in r.stdout
+        for extra in ([], ["--gpus", "2"]):
+            r = subprocess.run(bench + extra, capture_output=True, text=True, timeout=300, env=env)
+            assert r.returncode != 0 and "needs a GPU" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_spawn_ranks_sets_the_launcher_environment_and_reports_failures(tmp_path):
+    """`python bench.py --gpus N` starts its own ranks through spawn_ranks: every worker sees
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like under torch.distributed.run, only rank 0 owns
+    stdout, and one failing rank fails the job and ends its peers."""
+    import subprocess
+    import sys
+    from raytracing_amd import distributed as rdist
+    prog = ("import os, sys, pathlib; r = os.environ['RANK']; "
+            "pathlib.Path(sys.argv[1], 'rank' + r).write_text(' '.join(os.environ[k] for k in "
+            "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'))); print('out', r)")
+    script = tmp_path / "launch.py"
+    script.write_text(f"import sys\nsys.path.insert(0, {str(ROOT)!r})\nfrom raytracing_amd import distributed as rdist\n"
+                      f"sys.exit(rdist.spawn_ranks([sys.executable, '-c', {prog!r}, {str(tmp_path)!r}], 3, share_gpu=(sys.argv[1] == 'share')))\n")
+    for share in ("no", "share"):
+        r = subprocess.run([sys.executable, str(script), share], capture_output=True, text=True, timeout=120, cwd=str(ROOT))
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.split() == ["out", "0"]  # ranks 1.. are silent
+        seen = [(tmp_path / f"rank{k}").read_text().split() for k in range(3)]
+        assert [s[0] for s in seen] == ["0", "1", "2"] and all(s[2] == "3" and s[3] == "127.0.0.1" for s in seen)
+        assert [s[1] for s in seen] == (["0", "0", "0"] if share == "share" else ["0", "1", "2"])
+        assert len({s[4] for s in seen}) == 1
+    # rank 1 fails at once, the others would sleep for a minute: the job ends early and non-zero
+    import time
+    t0 = time.time()
+    rc = rdist.spawn_ranks([sys.executable, "-c", "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(60)"], 3)
+    assert rc == 7 and time.time() - t0 < 30
