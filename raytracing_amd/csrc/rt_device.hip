@@ -57,6 +57,11 @@ struct rt_handle {
     bool film_owned = false;
     uint32_t film_w = 0, film_h = 0;
 
+    // device staging of the boundary calls that move host arrays (film download / upload /
+    // quantize, the parity hooks): one buffer kept on the handle, grown when a call needs more
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+
     // stats
     rt_stats stats{};
     std::vector<EventPair> ev_pool;
@@ -78,6 +83,20 @@ int fail(rt_handle *h, const std::string &msg) {
         if (e_ != hipSuccess)                                                                \
             return fail(h, std::string(#call) + ": " + hipGetErrorString(e_));               \
     } while (0)
+
+// Device staging kept on the handle: grows to the largest request seen, freed by rt_destroy.
+int ensure_stage(rt_handle *h, size_t bytes, void **out) {
+    if (bytes > h->stage_bytes) {
+        RT_HIP(hipStreamSynchronize(h->stream)); // nothing in flight may still use the old buffer
+        if (h->stage) (void)hipFree(h->stage);
+        h->stage = nullptr, h->stage_bytes = 0;
+        const size_t want = (bytes + 0xFFFFu) & ~size_t(0xFFFFu);
+        RT_HIP(hipMalloc(&h->stage, want));
+        h->stage_bytes = want;
+    }
+    *out = h->stage;
+    return 0;
+}
 
 template <typename T> int upload(rt_handle *h, const T *src, size_t n, const T **dst) {
     *dst = nullptr;
@@ -601,6 +620,7 @@ void rt_destroy(rt_handle *h) {
     free_scene(h);
     free_queue(h);
     if (h->film && h->film_owned) (void)hipFree(h->film);
+    if (h->stage) (void)hipFree(h->stage);
     if (h->d_ctrl) (void)hipFree(h->d_ctrl);
     if (h->d_sc) (void)hipFree(h->d_sc);
     if (h->d_cam) (void)hipFree(h->d_cam);
@@ -919,12 +939,13 @@ int rt_film_download(rt_handle *h, float *rgb, float scale) {
     if (!h->film) return fail(h, "rt_film_download: no film");
     if (!rgb) return fail(h, "rt_film_download: null destination");
     uint32_t npix = h->film_w * h->film_h;
-    float *tmp = nullptr;
-    RT_HIP(hipMalloc((void **)&tmp, size_t(npix) * 3 * sizeof(float)));
+    void *stage = nullptr;
+    if (ensure_stage(h, size_t(npix) * 3 * sizeof(float), &stage)) return -1;
+    float *tmp = static_cast<float *>(stage);
     k_film_pack<<<(npix + 255) / 256, 256, 0, h->stream>>>(h->film, h->film + npix, h->film + 2 * size_t(npix), npix, scale, tmp);
-    hipError_t e = hipMemcpyAsync(rgb, tmp, size_t(npix) * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb, tmp, size_t(npix) * 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(tmp);
     if (e != hipSuccess) return fail(h, std::string("rt_film_download: ") + hipGetErrorString(e));
     return 0;
 }
@@ -937,36 +958,43 @@ int rt_film_upload(rt_handle *h, const float *rgb, uint32_t w, uint32_t hgt) {
         return fail(h, "rt_film_upload: size differs from the bound film");
     if (ensure_film(h, w, hgt)) return -1;
     const uint32_t npix = w * hgt;
-    float *tmp = nullptr;
-    RT_HIP(hipMalloc((void **)&tmp, size_t(npix) * 3 * sizeof(float)));
+    void *stage = nullptr;
+    if (ensure_stage(h, size_t(npix) * 3 * sizeof(float), &stage)) return -1;
+    float *tmp = static_cast<float *>(stage);
     hipError_t e = hipMemcpyAsync(tmp, rgb, size_t(npix) * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         k_film_unpack<<<(npix + 255) / 256, 256, 0, h->stream>>>(tmp, npix, h->film, h->film + npix, h->film + 2 * size_t(npix));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(tmp);
     if (e != hipSuccess) return fail(h, std::string("rt_film_upload: ") + hipGetErrorString(e));
     return 0;
 }
+
+namespace {
+// film sums -> packed bytes in `packed` (device) -> rgb8 (host)
+int quantize_into(rt_handle *h, const char *who, uint32_t *packed, uint8_t *rgb8, double scale, uint32_t gamma) {
+    const uint32_t npix = h->film_w * h->film_h;
+    const uint32_t groups = (npix + 3u) / 4u;
+    k_film_quantize<<<(groups + 255) / 256, 256, 0, h->stream>>>(h->film, h->film + npix, h->film + 2 * size_t(npix), npix, scale,
+                                                                gamma, packed);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb8, packed, size_t(npix) * 3, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(h, std::string(who) + ": " + hipGetErrorString(e));
+    return 0;
+}
+} // namespace
 
 int rt_film_quantize(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma) {
     if (!h) return -1;
     RT_HIP(hipSetDevice(h->device));
     if (!h->film) return fail(h, "rt_film_quantize: no film");
     if (!rgb8) return fail(h, "rt_film_quantize: null destination");
-    const uint32_t npix = h->film_w * h->film_h;
-    const uint32_t groups = (npix + 3u) / 4u;
-    uint32_t *tmp = nullptr;
-    RT_HIP(hipMalloc((void **)&tmp, size_t(groups) * 12));
-    k_film_quantize<<<(groups + 255) / 256, 256, 0, h->stream>>>(h->film, h->film + npix, h->film + 2 * size_t(npix), npix, scale,
-                                                                gamma, tmp);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(rgb8, tmp, size_t(npix) * 3, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(h, std::string("rt_film_quantize: ") + hipGetErrorString(e));
-    return 0;
+    const uint32_t groups = (h->film_w * h->film_h + 3u) / 4u;
+    void *stage = nullptr;
+    if (ensure_stage(h, size_t(groups) * 12, &stage)) return -1;
+    return quantize_into(h, "rt_film_quantize", static_cast<uint32_t *>(stage), rgb8, scale, gamma);
 }
 
 int rt_get_stats(rt_handle *h, rt_stats *out) {
@@ -1098,9 +1126,6 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (!h->have_scene) return fail(h, "rt_intersect_batch: no scene uploaded");
     if (n == 0) return 0;
     if (!o || !d || !hit || !prim || !t || !u || !v) return fail(h, "rt_intersect_batch: null array");
-    float *d_o = nullptr, *d_d = nullptr, *d_time = nullptr, *d_f = nullptr;
-    int *d_i = nullptr;
-    uint32_t *d_from = nullptr;
     std::vector<uint32_t> from;
     if (origin_prim) {
         from.resize(n);
@@ -1110,13 +1135,15 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
             from[i] = id < 0 ? RT_REF_NONE : h->prim_to_ref[id];
         }
     }
-    hipError_t e = hipMalloc((void **)&d_o, size_t(n) * 3 * sizeof(float));
-    if (e == hipSuccess && origin_prim) e = hipMalloc((void **)&d_from, size_t(n) * sizeof(uint32_t));
-    if (e == hipSuccess && origin_prim) e = hipMemcpyAsync(d_from, from.data(), size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_d, size_t(n) * 3 * sizeof(float));
-    if (e == hipSuccess && time) e = hipMalloc((void **)&d_time, size_t(n) * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_f, size_t(n) * 3 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_i, size_t(n) * 2 * sizeof(int));
+    // one staging buffer: o[3n] d[3n] time[n] from[n] | t,u,v[3n] hit,prim[2n]
+    void *stage = nullptr;
+    if (ensure_stage(h, size_t(n) * 13 * sizeof(float), &stage)) return -1;
+    float *d_o = static_cast<float *>(stage), *d_d = d_o + 3 * size_t(n), *d_time = time ? d_d + 3 * size_t(n) : nullptr;
+    uint32_t *d_from = origin_prim ? reinterpret_cast<uint32_t *>(d_o + 7 * size_t(n)) : nullptr;
+    float *d_f = d_o + 8 * size_t(n);
+    int *d_i = reinterpret_cast<int *>(d_o + 11 * size_t(n));
+    hipError_t e = hipSuccess;
+    if (origin_prim) e = hipMemcpyAsync(d_from, from.data(), size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_o, o, size_t(n) * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_d, d, size_t(n) * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && time) e = hipMemcpyAsync(d_time, time, size_t(n) * sizeof(float), hipMemcpyHostToDevice, h->stream);
@@ -1140,8 +1167,6 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     if (e == hipSuccess) e = hipMemcpyAsync(u, d_f + n, size_t(n) * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(v, d_f + 2 * size_t(n), size_t(n) * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    for (void *p : {(void *)d_o, (void *)d_d, (void *)d_time, (void *)d_f, (void *)d_i, (void *)d_from})
-        if (p) (void)hipFree(p);
     if (e != hipSuccess) return fail(h, std::string("rt_intersect_batch: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1158,11 +1183,11 @@ int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *p
     for (uint32_t i = 0; i < n; ++i)
         if (pixel[i] >= dc.npix || stratum[i] >= dc.sqrt_spp * dc.sqrt_spp)
             return fail(h, "rt_camera_rays: pixel or stratum out of range");
-    uint32_t *d_u = nullptr;
-    float *d_f = nullptr;
-    hipError_t e = hipMalloc((void **)&d_u, size_t(n) * 2 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_f, size_t(n) * 7 * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_u, pixel, size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
+    void *stage = nullptr;
+    if (ensure_stage(h, size_t(n) * 9 * sizeof(float), &stage)) return -1;
+    uint32_t *d_u = static_cast<uint32_t *>(stage);
+    float *d_f = reinterpret_cast<float *>(d_u + 2 * size_t(n));
+    hipError_t e = hipMemcpyAsync(d_u, pixel, size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_u + n, stratum, size_t(n) * 4, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         k_camera_rays<<<(n + 255) / 256, 256, 0, h->stream>>>(h->d_cam, uint32_t(p->seed), uint32_t(p->seed >> 32), n, d_u, d_u + n,
@@ -1173,8 +1198,6 @@ int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *p
     if (e == hipSuccess) e = hipMemcpyAsync(d, d_f + 3 * size_t(n), size_t(n) * 12, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(time, d_f + 6 * size_t(n), size_t(n) * 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (d_u) (void)hipFree(d_u);
-    if (d_f) (void)hipFree(d_f);
     if (e != hipSuccess) return fail(h, std::string("rt_camera_rays: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1186,18 +1209,16 @@ int rt_eval_texture(rt_handle *h, uint32_t tex, uint32_t n, const float *uvp, fl
     if (tex >= h->n_textures) return fail(h, "rt_eval_texture: texture id out of range");
     if (n == 0) return 0;
     if (!uvp || !rgb) return fail(h, "rt_eval_texture: null array");
-    float *d_in = nullptr, *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_in, size_t(n) * 5 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, size_t(n) * 3 * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, uvp, size_t(n) * 20, hipMemcpyHostToDevice, h->stream);
+    void *stage = nullptr;
+    if (ensure_stage(h, size_t(n) * 8 * sizeof(float), &stage)) return -1;
+    float *d_in = static_cast<float *>(stage), *d_out = d_in + 5 * size_t(n);
+    hipError_t e = hipMemcpyAsync(d_in, uvp, size_t(n) * 20, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         k_eval_texture<<<(n + 255) / 256, 256, 0, h->stream>>>(h->d_sc, tex, n, d_in, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(rgb, d_out, size_t(n) * 12, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(h, std::string("rt_eval_texture: ") + hipGetErrorString(e));
     return 0;
 }
@@ -1207,18 +1228,16 @@ int rt_philox(rt_handle *h, uint32_t n, const uint32_t *ctr, const uint32_t key[
     RT_HIP(hipSetDevice(h->device));
     if (n == 0) return 0;
     if (!ctr || !key || !out) return fail(h, "rt_philox: null array");
-    uint32_t *d_in = nullptr, *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_in, size_t(n) * 16);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, size_t(n) * 16);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, ctr, size_t(n) * 16, hipMemcpyHostToDevice, h->stream);
+    void *stage = nullptr;
+    if (ensure_stage(h, size_t(n) * 32, &stage)) return -1;
+    uint32_t *d_in = static_cast<uint32_t *>(stage), *d_out = d_in + 4 * size_t(n);
+    hipError_t e = hipMemcpyAsync(d_in, ctr, size_t(n) * 16, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         k_philox<<<(n + 255) / 256, 256, 0, h->stream>>>(n, d_in, key[0], key[1], d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, size_t(n) * 16, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(h, std::string("rt_philox: ") + hipGetErrorString(e));
     return 0;
 }
