@@ -270,6 +270,16 @@ int rt_film_upload(rt_handle *h, const float *rgb, uint32_t width, uint32_t heig
  * export.rs:80), then as_rgb_ints: clamp to [0,1], * 255, truncate (color.rs:148-155).
  * Evaluated in f64 on the fp32 sums. */
 int rt_film_quantize(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma);
+/* rt_film_quantize for callers that cannot allocate.  No counterpart in the reference: it is for
+ * code under HIP graph capture, tight serving / preview loops and harnesses that forbid
+ * hipMalloc.  Same arguments, same bytes.  The packed image is staged in a fixed device array
+ * that every GPU holds from library load to process exit (24.9 MB), so the film may have at most
+ * RT_NOALLOC_MAX_PIXELS pixels (3840 x 2160); a larger film is refused with an error.  The call
+ * makes no hipMalloc / hipFree or other allocating call.  All handles of one GPU share that
+ * array: two such calls that overlap on one GPU race, and the array keeps the last call's bytes
+ * (every word the copy reads is overwritten first, so nothing needs clearing). */
+#define RT_NOALLOC_MAX_PIXELS 8294400u
+int rt_film_quantize_noalloc(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma);
 int rt_get_stats(rt_handle *h, rt_stats *out);
 
 /* Parity hook: closest hit of the uploaded world for n host rays (o,d: n*3; time: n or NULL).

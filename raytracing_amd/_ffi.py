@@ -119,6 +119,7 @@ SIGNATURES = {
     "rt_film_download": (C.c_int, [_vp, P(f32), f32]),
     "rt_film_upload": (C.c_int, [_vp, P(f32), u32, u32]),
     "rt_film_quantize": (C.c_int, [_vp, P(C.c_uint8), f64, u32]),
+    "rt_film_quantize_noalloc": (C.c_int, [_vp, P(C.c_uint8), f64, u32]),
     "rt_get_stats": (C.c_int, [_vp, P(RtStats)]),
     "rt_intersect_batch": (C.c_int, [_vp, u32, P(f32), P(f32), P(f32), P(i32), f32, f32, P(i32), P(i32), P(f32), P(f32), P(f32)]),
     "rt_camera_rays": (C.c_int, [_vp, P(RtCamera), P(RtRenderParams), u32, P(u32), P(u32), P(f32), P(f32), P(f32)]),

@@ -333,12 +333,17 @@ class Device:
                     "rt_film_download")
         return out
 
-    def film_rgb8(self, scale, gamma=False):
+    def film_rgb8(self, scale, gamma=False, no_alloc=False, out=None):
         """(H, W, 3) uint8: the reference's 8-bit rule applied to sums * scale on the device
-        (gamma=True is what PpmWriter writes, False what PngWriter writes)."""
-        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
-        self._check(self.lib.rt_film_quantize(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(scale),
-                                              1 if gamma else 0), "rt_film_quantize")
+        (gamma=True is what PpmWriter writes, False what PngWriter writes).  no_alloc=True takes
+        the entry point that stages through the library's fixed device array (films up to
+        3840 x 2160) and makes no allocating call; `out` receives the bytes if given."""
+        if out is None:
+            out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.flags.c_contiguous and out.size == self.height * self.width * 3
+        fn, name = (self.lib.rt_film_quantize_noalloc, "rt_film_quantize_noalloc") if no_alloc else \
+            (self.lib.rt_film_quantize, "rt_film_quantize")
+        self._check(fn(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(scale), 1 if gamma else 0), name)
         return out
 
     def film_upload(self, sums):

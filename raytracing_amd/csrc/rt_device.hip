@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,8 @@ struct rt_handle {
     // quantize, the parity hooks): one buffer kept on the handle, grown when a call needs more
     void *stage = nullptr;
     size_t stage_bytes = 0;
+    // this device's copy of `scratch` (below): rt_film_quantize_noalloc
+    uint32_t *noalloc_scratch = nullptr;
 
     // stats
     rt_stats stats{};
@@ -68,6 +71,14 @@ struct rt_handle {
     size_t ev_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_poll[2] = {nullptr, nullptr};
 };
+
+// Scratch of rt_film_quantize_noalloc, the entry point that allocates nothing: the packed 8-bit
+// image on its way to the host.  Every GPU the library runs on holds its own copy of this array
+// from the moment the code object is loaded until the process ends.  The name is a host-side
+// stand-in, not a device address: host code uses the pointer hipGetSymbolAddress returns for the
+// current device (scratch_for_device), never the name.
+constexpr uint32_t NOALLOC_MAX_PIXELS = 3840u * 2160u; // one UHD frame: 24.9 MB of bytes
+static __device__ __align__(256) uint32_t scratch[(NOALLOC_MAX_PIXELS + 3u) / 4u * 3u];
 
 namespace {
 
@@ -83,6 +94,24 @@ int fail(rt_handle *h, const std::string &msg) {
         if (e_ != hipSuccess)                                                                \
             return fail(h, std::string(#call) + ": " + hipGetErrorString(e_));               \
     } while (0)
+
+// The address of `scratch` on a device, looked up once per device with that device current.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+uint32_t *g_scratch_ptr[MAX_DEVICES] = {};
+int scratch_for_device(rt_handle *h, int device, uint32_t **out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(h, "device id beyond the scratch table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        RT_HIP(hipSetDevice(device));
+        RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(h, "hipGetSymbolAddress(scratch) returned a null pointer");
+        g_scratch_ptr[device] = static_cast<uint32_t *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
 
 // Device staging kept on the handle: grows to the largest request seen, freed by rt_destroy.
 int ensure_stage(rt_handle *h, size_t bytes, void **out) {
@@ -609,6 +638,11 @@ int rt_create(int device_id, rt_handle **out) {
         return -1;
     }
     nh->own_stream = true;
+    if (scratch_for_device(nh, device_id, &nh->noalloc_scratch)) {
+        g_create_error = "rt_create: " + nh->err;
+        rt_destroy(nh);
+        return -1;
+    }
     *out = nh;
     return 0;
 }
@@ -995,6 +1029,19 @@ int rt_film_quantize(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma) 
     void *stage = nullptr;
     if (ensure_stage(h, size_t(groups) * 12, &stage)) return -1;
     return quantize_into(h, "rt_film_quantize", static_cast<uint32_t *>(stage), rgb8, scale, gamma);
+}
+
+int rt_film_quantize_noalloc(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma) {
+    if (!h) return -1;
+    RT_HIP(hipSetDevice(h->device));
+    if (!h->film) return fail(h, "rt_film_quantize_noalloc: no film");
+    if (!rgb8) return fail(h, "rt_film_quantize_noalloc: null destination");
+    if (uint64_t(h->film_w) * h->film_h > NOALLOC_MAX_PIXELS)
+        return fail(h, "rt_film_quantize_noalloc: film of " + std::to_string(uint64_t(h->film_w) * h->film_h) +
+                           " pixels exceeds the fixed scratch of " + std::to_string(NOALLOC_MAX_PIXELS) +
+                           " pixels (3840 x 2160); use rt_film_quantize");
+    // the kernel overwrites every word of the scratch that the copy reads: nothing to clear
+    return quantize_into(h, "rt_film_quantize_noalloc", h->noalloc_scratch, rgb8, scale, gamma);
 }
 
 int rt_get_stats(rt_handle *h, rt_stats *out) {

@@ -1,0 +1,65 @@
+"""rt_film_quantize_noalloc, the one entry point that allocates nothing: it stages the packed
+8-bit image in the library's fixed device array instead of a buffer it allocates.  Its bytes
+must equal rt_film_quantize's on the same film -- on two calls in a row, the second with a
+smaller film (the array still holds the first call's bytes) -- and a film beyond the fixed size
+must be refused."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import _ffi
+
+
+def _render(dev, width, spp, seed):
+    sb = ra.SceneBuilder()
+    cam = ra.scenes.cornell_book3(sb, width=width, spp=spp)
+    dev.upload(sb)
+    dev.film_resize(width, width)
+    dev.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=seed)
+    return cam
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_no_alloc_quantize_equals_the_allocating_entry_point_twice_in_a_row():
+    dev = ra.Device(0)
+    try:
+        lib = _ffi.lib
+        for width, spp, seed in [(192, 9, 3), (80, 4, 4)]:  # the second film is smaller
+            cam = _render(dev, width, spp, seed)
+            npix = width * width
+            for gamma in (0, 1):
+                scale = 1.0 / cam.effective_spp
+                want = np.zeros(npix * 3, np.uint8)
+                got = np.full(npix * 3 + 64, 0xA5, np.uint8)  # guard bytes behind the image
+                u8p = C.POINTER(C.c_uint8)
+                assert lib.rt_film_quantize(dev.h, want.ctypes.data_as(u8p), C.c_double(scale), gamma) == 0
+                assert lib.rt_film_quantize_noalloc(dev.h, got.ctypes.data_as(u8p), C.c_double(scale), gamma) == 0, \
+                    lib.rt_last_error(dev.h).decode()
+                assert want.max() > 0
+                assert np.array_equal(got[:npix * 3], want)  # bytes: bit-exact
+                assert (got[npix * 3:] == 0xA5).all()
+        # the wrapper takes the same path
+        assert np.array_equal(dev.film_rgb8(0.25, no_alloc=True), dev.film_rgb8(0.25))
+        # a second handle on the same GPU shares the array
+        dev2 = ra.Device(0)
+        try:
+            cam = _render(dev2, 64, 4, 9)
+            assert np.array_equal(dev2.film_rgb8(0.25, gamma=True, no_alloc=True), dev2.film_rgb8(0.25, gamma=True))
+        finally:
+            dev2.close()
+        assert np.array_equal(dev.film_rgb8(0.25, no_alloc=True), dev.film_rgb8(0.25))
+        # beyond the fixed array: refused with a message, the allocating entry point still works
+        dev.film_resize(3841, 2160)
+        out = np.zeros(3841 * 2160 * 3, np.uint8)
+        rc = _ffi.lib.rt_film_quantize_noalloc(dev.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(1.0), 0)
+        assert rc < 0 and "exceeds the fixed scratch" in _ffi.lib.rt_last_error(dev.h).decode()
+        assert _ffi.lib.rt_film_quantize(dev.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(1.0), 0) == 0
+        # exactly the maximum is accepted
+        dev.film_resize(3840, 2160)
+        assert _ffi.lib.rt_film_quantize_noalloc(dev.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(1.0), 0) == 0
+        assert not out[:3840 * 2160 * 3].any()
+    finally:
+        dev.close()
