@@ -80,7 +80,10 @@ class _Node:
 class TomlRecorder:
     """SceneBuilder's construction interface; records instead of building."""
 
-    def __init__(self):
+    def __init__(self, shared_images=False):
+        # shared_images: an image equal to the earth texture is referenced at ../textures/earth.png
+        # (files written under scenes/<name>/) instead of being written beside the scene file
+        self.shared_images = shared_images
         self.textures, self.materials, self.objects = [], [], []
         self.images = {}  # texture index -> uint8 array
         self.world = self.lights = None
@@ -98,7 +101,14 @@ class TomlRecorder:
 
     def tex_image(self, rgb):
         i = len(self.textures)
-        self.images[i] = np.ascontiguousarray(rgb, dtype=np.uint8)
+        img = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if self.shared_images:
+            from . import scenes
+            if img.shape == (1024, 2048, 3) and np.array_equal(img, scenes.earth_texture()):
+                # the earth image lives once under scenes/textures; scene files sit one level below scenes/
+                self.textures.append(dict(type="image", path="../textures/earth.png"))
+                return i
+        self.images[i] = img
         self.textures.append(dict(type="image", path=f"texture_{i:04d}.png"))
         return i
 

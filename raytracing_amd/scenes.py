@@ -110,9 +110,21 @@ def book1_final(sb: SceneBuilder, width=1200, spp=500, grid=11):
     return cam
 
 
+EARTH_PNG = _SCENES_DIR / "textures" / "earth.png"
+
+
+def earth_texture():
+    """The reference's earth image (assets/textures/earth.png, 2048x1024 RGB8; the file under
+    scenes/textures is that file byte for byte), decoded by the library's own PNG reader -- the
+    loader behind ImageTexture::load (texture.rs:95-122)."""
+    from . import imageio
+    return imageio.read_png(EARTH_PNG)
+
+
 def synthetic_earth(width=2048, height=1024):
-    """Deterministic stand-in for the reference's assets/textures/earth.png (same size and
-    format: RGB8, 2048x1024); low-frequency 'continents' over an ocean gradient."""
+    """Deterministic image of any size in the earth texture's format (RGB8): low-frequency
+    'continents' over an ocean gradient.  For miniatures of the Book-2 scene in tests; the
+    workload itself uses earth_texture()."""
     rng = np.random.Generator(np.random.Philox(key=0xEA27))
     yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
     u, v = xx / width * 2 * np.pi, yy / height * np.pi
@@ -158,7 +170,7 @@ def book2_final(sb: SceneBuilder, width=800, spp=10000, boxes_per_side=20, cloud
     world.append(sb.medium(boundary, 0.2, (0.2, 0.4, 0.9)))
     boundary2 = sb.sphere((0.0, 0.0, 0.0), 5000.0, sb.dielectric(1.5))
     world.append(sb.medium(boundary2, 0.0001, (1.0, 1.0, 1.0)))
-    earth_img = synthetic_earth() if earth is None else earth
+    earth_img = earth_texture() if earth is None else earth
     world.append(sb.sphere((400.0, 200.0, 400.0), 100.0, sb.lambertian(sb.tex_image(earth_img))))
     vec, perm = perlin_tables()
     world.append(sb.sphere((220.0, 280.0, 300.0), 80.0, sb.lambertian(sb.tex_noise(0.2, vec, perm))))
@@ -185,19 +197,23 @@ def stress(sb: SceneBuilder, n_prims=1_000_000, width=3840, height=2160, spp=409
     mat_pick = rng.random(n_prims)
     size = rng.random(n_prims)
     dirs = rng.standard_normal((n_prims, 2, 3))
+    # quad edges for all primitives at once (a million per-primitive numpy calls take a minute)
+    edge = 0.1 + 0.9 * size
+    u_all = dirs[:, 0] / np.sqrt((dirs[:, 0] ** 2).sum(axis=1))[:, None] * edge[:, None]
+    v_all = np.cross(u_all, dirs[:, 1])
+    v_all = v_all / np.sqrt((v_all ** 2).sum(axis=1))[:, None] * edge[:, None]
+    radius = 0.05 + 0.45 * size
+    lam = np.minimum((mat_pick / 0.7 * 32).astype(np.int64), 10 ** 9) % 32
+    met = ((mat_pick - 0.7) / 0.2 * 8).astype(np.int64) % 8
+    centers_l, u_l, v_l = centers.tolist(), u_all.tolist(), v_all.tolist()
     objs = []
     for i in range(n_prims):
         m = mat_pick[i]
-        mat = mats[int(m / 0.7 * 32) % 32] if m < 0.7 else (metals[int((m - 0.7) / 0.2 * 8) % 8] if m < 0.9 else glass)
-        c = centers[i]
+        mat = mats[lam[i]] if m < 0.7 else (metals[met[i]] if m < 0.9 else glass)
         if kind[i] < 0.5:
-            objs.append(sb.sphere(tuple(c), 0.05 + 0.45 * size[i], mat))
+            objs.append(sb.sphere(centers_l[i], radius[i], mat))
         else:
-            e = 0.1 + 0.9 * size[i]
-            u = dirs[i, 0] / np.linalg.norm(dirs[i, 0]) * e
-            v = np.cross(u, dirs[i, 1])
-            v = v / np.linalg.norm(v) * e
-            objs.append(sb.quad(tuple(c), tuple(u), tuple(v), mat))
+            objs.append(sb.quad(centers_l[i], u_l[i], v_l[i], mat))
     sb.set_world(sb.list([sb.bvh(objs)]))
     sb.set_lights(None)
     cam = CameraSettings()

@@ -15,19 +15,19 @@ from raytracing_amd.scene_toml import TomlRecorder  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default=str(ROOT / "scenes"))
 ap.add_argument("--stress-prims", type=int, default=3000)
-ap.add_argument("--earth", default="512x256", help="size of the synthetic earth texture of book2_final")
+ap.add_argument("--earth", default="", help="WxH of a synthetic earth texture for book2_final instead of the real image")
 args = ap.parse_args()
 out = Path(args.out)
-ew, eh = (int(x) for x in args.earth.split("x"))
+earth = ra.scenes.synthetic_earth(*(int(x) for x in args.earth.split("x"))) if args.earth else None
 jobs = {
     "cornell_main": (ra.scenes.cornell_main, {}),
     "book1_final": (ra.scenes.book1_final, {}),
     "cornell_book3": (ra.scenes.cornell_book3, {}),
-    "book2_final": (ra.scenes.book2_final, dict(earth=ra.scenes.synthetic_earth(ew, eh))),
+    "book2_final": (ra.scenes.book2_final, dict(earth=earth)),
     "stress": (ra.scenes.stress, dict(n_prims=args.stress_prims, extent=100.0 if args.stress_prims >= 100000 else 6.0)),
 }
 for name, (fn, kw) in jobs.items():
-    rec = TomlRecorder()
+    rec = TomlRecorder(shared_images=True)
     cam = fn(rec, **kw)
     d = out / name
     d.mkdir(parents=True, exist_ok=True)
