@@ -55,6 +55,85 @@ def ray_batch(osb, cam, n, seed, bbox):
     return O[good], D[good], T[good], F[good]
 
 
+def sphere_ids(host):
+    d = host.flatten().contents
+    return np.array([d.spheres[i].prim_id for i in range(d.n_spheres)], dtype=np.int64)
+
+
+def check_intersection_parity(device, host, osb, cam, bbox, coord_scale, name="", n=65536, seed=3):
+    """The bar of the fixed-ray-batch check on the scene uploaded to `device`: identical hit/miss
+    and primitive id except where the oracle itself is unstable or two primitives tie, t within
+    1e-5 relative (grazing hits: within 8 ulp of the coordinate scale from the oracle's surface),
+    u and v within 2e-3."""
+    o, d, tm, frm = ray_batch(osb, cam, n, seed=seed, bbox=bbox)
+    assert len(o) > 0.9 * n
+    hit, prim, t, u, v = device.intersect_batch(o, d, tm, origin_prim=frm)
+    h2, p2, t2, u2, v2, second, nrm = orc.intersect_batch(osb, o, d, tm, want_normal=True)
+    assert 0.2 < h2.mean() <= 1.0
+    mism = np.nonzero((hit != h2) | (prim != p2))[0]
+    if len(mism):
+        unstable = unstable_rays(osb, o, d, tm, mism, coord_scale)
+        # a mismatch is tolerated only where the oracle's own answer is unstable under
+        # fp32-sized perturbations, or where two primitives are hit at the same t to fp32
+        # resolution (coincident faces, shared edges)
+        with np.errstate(invalid="ignore"):
+            tie = np.abs(second[mism] - t2[mism]) <= 1e-5 * np.abs(t2[mism])
+        both_hit = (hit[mism] == 1) & (h2[mism] == 1)
+        near_t = both_hit & (np.abs(t[mism] - t2[mism]) <= 1e-5 * np.abs(t2[mism]))
+        unexplained = ~(unstable | tie | near_t)
+        assert not unexplained.any(), (name, mism[unexplained][:10], prim[mism][unexplained][:10], p2[mism][unexplained][:10],
+                                       t[mism][unexplained][:10], t2[mism][unexplained][:10], o[mism][unexplained][:3],
+                                       d[mism][unexplained][:3])
+    # Coincident surfaces (neighbouring boxes share faces, a box stands on the floor) are met at
+    # the same t: which of the two is reported depends on the visiting order, the reference's
+    # being left child first.  Such rays must agree on t; everything else stays below 1e-3.
+    n_tie = int((tie & near_t).sum()) if len(mism) else 0
+    # A grazing ray off a plane whose coordinate fp32 cannot hold exactly (a box top at y = 94.9...):
+    # the batch's fp32 origin sits a few 1e-6 off the plane, so the f64 oracle meets the plane it
+    # starts on again beyond its 0.001 bound.  The device never re-tests the planar primitive a ray
+    # leaves (in a render the oracle's own f64 origins are on the plane and it does not either);
+    # it must then report what the oracle has as its second hit.
+    n_rehit = 0
+    if len(mism):
+        with np.errstate(invalid="ignore"):
+            gpu_is_second = np.where(np.isfinite(second[mism]), (hit[mism] == 1) & (np.abs(t[mism] - second[mism]) <= 1e-5 * np.abs(second[mism])),
+                                     hit[mism] == 0)
+        rehit = (frm[mism] >= 0) & (p2[mism] == frm[mism]) & gpu_is_second & ~(tie & near_t)
+        n_rehit = int(rehit.sum())
+    assert len(mism) - n_tie - n_rehit <= 1e-3 * len(o), (len(mism), n_tie, n_rehit)
+    ok = np.nonzero((hit == 1) & (h2 == 1) & (prim == p2))[0]
+    err = np.abs(t[ok] - t2[ok])
+    rel = err / np.abs(t2[ok])
+    # Bar: 1e-5 relative.  Where a ray meets a surface at grazing incidence, or starts within
+    # fp32 resolution of the surface it hits, the along-ray error is the coordinate resolution
+    # divided by |cos|: such hits are held to a distance from the oracle's hit surface of 8 ulp
+    # of the coordinate scale, or must be as unstable in the oracle itself.
+    dn = np.abs(np.einsum("ij,ij->i", nrm[ok], d[ok].astype(np.float64)))
+    surf_dist = err * dn
+    fine = (rel <= 1e-5) | (surf_dist <= 8 * 2.0 ** -23 * coord_scale)
+    if not fine.all():
+        left = np.nonzero(~fine)[0]
+        wobble = unstable_t(osb, o, d, tm, ok[left], coord_scale)
+        still = rel[left] > 4.0 * wobble
+        assert not still.any(), (ok[left][still][:10], rel[left][still][:10], wobble[still][:10])
+    general = frm[ok] != p2[ok]  # a ray re-entering the sphere it starts on is covered above
+    # 1e-5 relative, or -- a short ray in a large scene: t is small against the coordinates its
+    # hit point is made of -- a hit point within ONE fp32 ulp of the coordinate scale of the oracle's
+    # surface; and on its own the 1e-5 bar holds for 99 % of the hits in every scene
+    within = (rel <= 1e-5) | (surf_dist <= 2.0 ** -23 * coord_scale)
+    assert within[general].mean() > 0.995, float(within[general].mean())
+    assert (rel[general] <= 1e-5).mean() > 0.99, float((rel[general] <= 1e-5).mean())
+    assert np.median(rel) < 2e-7
+    uv_ok = ok[np.isfinite(u2[ok]) & (rel <= 1e-5)]
+    du = np.abs(u[uv_ok] - u2[uv_ok])
+    du = np.minimum(du, 1.0 - du)  # a sphere's u wraps at the atan2 seam (hittable.rs:155)
+    on_sphere = np.isin(p2[uv_ok], sphere_ids(host))
+    du = np.where(on_sphere, du * np.sin(np.pi * v2[uv_ok]), du)  # longitude is ill-conditioned at the poles
+    assert du.max() < 2e-3 and np.abs(v[uv_ok] - v2[uv_ok]).max() < 2e-3
+    assert np.median(du) < 1e-5
+    return dict(rays=len(o), mismatches=int(len(mism)), same_t_ties=n_tie, origin_plane_rehits=n_rehit, median_rel_t=float(np.median(rel)), frac_t_within_1e5=float((rel[general] <= 1e-5).mean()))
+
+
 def unstable_rays(osb, o, d, tm, idx, coord_scale, tmin=0.001, n_try=24, ulps=4.0, seed=0):
     """For rays idx: True where the ORACLE's own answer (hit, prim) flips when origin and
     direction move by a few fp32 ulps of the scene's coordinate scale -- edge grazes, ties and
