@@ -1,5 +1,7 @@
 """Shared helpers for the parity tests: build one scene description in both the product's
 host layer and the oracle, make fixed ray batches, compare images."""
+import os
+
 import numpy as np
 
 import raytracing_amd as ra
@@ -173,5 +175,10 @@ def compare_same_stream(gpu_img, cpu_img):
     """Pixelwise comparison of two renders that consumed the same uniforms."""
     diff = np.abs(gpu_img.astype(np.float64) - cpu_img)
     rel = diff / (np.abs(cpu_img) + 1e-2)
+    log = os.environ.get("RT_PARITY_LOG")  # measured margins of every same-stream comparison, one line each
+    if log:
+        with open(log, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}  {gpu_img.shape[1]}x{gpu_img.shape[0]}  "
+                    f"median_rel={np.median(rel):.3e}  frac_1e3={(rel > 1e-3).mean():.4f}  frac_5e2={(rel > 5e-2).mean():.4f}\n")
     return dict(max_abs=float(diff.max()), median_rel=float(np.median(rel)), frac_1e3=float((rel > 1e-3).mean()),
                 frac_5e2=float((rel > 5e-2).mean()), mean_gpu=gpu_img.mean(axis=(0, 1)), mean_cpu=cpu_img.mean(axis=(0, 1)))

@@ -166,7 +166,7 @@ def test_antialiasing_disc_camera_rays_and_render(device):
     gpu = device.film(1.0 / cam.effective_spp)
     film, _, _ = orc.render(osb, disc, mode=mode, seed=5)
     rr = helpers.compare_same_stream(gpu, film / cam.effective_spp)
-    assert rr["median_rel"] < 1e-4 and rr["frac_5e2"] < 0.08, rr
+    assert rr["median_rel"] < 8e-8 and rr["frac_5e2"] < FORKED, rr
     device.render(cam.build(), mode=mode, seed=5)  # the square sampler gives another image
     assert not np.allclose(device.film(0.5 / cam.effective_spp), gpu, rtol=1e-3)
 
@@ -189,8 +189,16 @@ PIPELINES = {"persistent": {}, "lane-bound": dict(regroup=False), "regrouped": d
 FLAT_WORLDS = ("c1", "c3")
 
 
+# Bounds: at most twice what was measured (profiles/r2_parity_margins.txt: median relative difference
+# 3.7e-8 / 1.0e-7 / 4.0e-8 / 4.3e-8 / 9.9e-5, values beyond 5 %: none in c1-c4, 1.8 % in c5); FORKED
+# stands for "none measured": a handful of values of one forked path, 5e-4 of the frame.  The stress
+# scene differs because its paths chain mirror and glass bounces off spheres down to r = 0.05: a
+# rounding difference grows by distance / radius at every such bounce.
+FORKED = 5e-4
+
+
 @pytest.mark.parametrize("pipeline", list(PIPELINES))
-@pytest.mark.parametrize("name,med,frac", [("c1", 1e-5, 0.01), ("c3", 1e-4, 0.06), ("c2", 1e-4, 0.08), ("c4", 1e-4, 0.08), ("c5", 1e-4, 0.10)])
+@pytest.mark.parametrize("name,med,frac", [("c1", 8e-8, FORKED), ("c3", 2e-7, FORKED), ("c2", 8e-8, FORKED), ("c4", 9e-8, FORKED), ("c5", 2e-4, 0.036)])
 def test_render_same_stream_pixelwise(device, name, med, frac, pipeline):
     """Same uniforms on both sides: almost every pixel agrees to fp32 accuracy; the few that do
     not are paths that forked at an fp32-vs-f64 decision (edge, rejection loop, Schlick draw)."""
@@ -228,7 +236,7 @@ def test_render_matches_committed_golden_images(device):
         gpu = device.film(1.0 / cam.effective_spp)
         want = np.load(GOLD / f"{name}_oracle_64x64_spp16.npy")
         r = helpers.compare_same_stream(gpu, want.astype(np.float64))
-        assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.06, r
+        assert r["median_rel"] < 2e-7 and r["frac_5e2"] < FORKED, r
 
 
 @pytest.mark.parametrize("name", ["c1", "c3"])
@@ -403,7 +411,7 @@ def test_max_depth_one_and_sky_background(device):
         gpu = device.film(1 / 16)
         film, _, cnt = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=1)
         r = helpers.compare_same_stream(gpu, film / 16)
-        assert r["median_rel"] < 1e-5 and r["frac_5e2"] < 0.03, r
+        assert r["median_rel"] < 5e-8 and r["frac_5e2"] < FORKED, r
         assert st.segments == cnt["segments"] - cnt["zero_weight_segments"]
         if depth == 1:
             assert st.segments == st.camera_rays
@@ -469,7 +477,7 @@ def test_image_textured_quads_in_a_flat_world(device, pipeline):
     gpu = device.film(1.0 / 16)
     film, _, _ = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=3)
     r = helpers.compare_same_stream(gpu, film / 16)
-    assert gpu.max() > 0.1 and r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.05, r
+    assert gpu.max() > 0.1 and r["median_rel"] < 4e-8 and r["frac_5e2"] < FORKED, r
     o = np.tile(np.array([[0.3, 0.2, 2.5]], np.float32), (2000, 1))
     d = np.concatenate([rng.random((2000, 2)) * 4 - 2, np.full((2000, 1), -5.5)], axis=1).astype(np.float32)
     hit, prim, t, u, v = device.intersect_batch(o, d, np.zeros(2000, np.float32))
@@ -545,7 +553,7 @@ def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device
         device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=9, **PIPELINES[pipeline])
         film, _, _ = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=9)
         r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
-        assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.05, (pipeline, r)
+        assert r["median_rel"] < 1.2e-7 and r["frac_5e2"] < FORKED, (pipeline, r)
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINES))
@@ -582,7 +590,7 @@ def test_flat_world_with_every_material_and_a_medium(device, pipeline):
     film, _, cnt = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=5)
     r = helpers.compare_same_stream(gpu, film / 16)
     assert np.isfinite(gpu).all() and gpu.max() > 0.1
-    assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.08, r
+    assert r["median_rel"] < 4e-7 and r["frac_5e2"] < FORKED, r
     assert np.allclose(r["mean_gpu"], r["mean_cpu"], rtol=0.03), r
     assert st.camera_rays == cnt["camera_rays"]
     want = cnt["segments"] - cnt["zero_weight_segments"]
@@ -621,7 +629,7 @@ def test_glass_sphere_inside_segments(device, cut):
         device.film_clear()
         st = device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=4, **PIPELINES[pipeline])
         r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
-        assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.08, (pipeline, r)
+        assert r["median_rel"] < 2e-7 and r["frac_5e2"] < FORKED, (pipeline, r)
         segs[pipeline] = st.segments
     want = cnt["segments"] - cnt["zero_weight_segments"]
     assert abs(segs["regrouped"] - want) <= 1e-2 * want and abs(segs["regrouped"] - segs["lane-bound"]) <= 2e-3 * want, (segs, want)
@@ -655,7 +663,7 @@ def test_flat_world_too_large_for_the_scene_tables(device):
         device.film_clear()
         st = device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=6, **PIPELINES[pipeline])
         r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
-        assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.06, (pipeline, r)
+        assert r["median_rel"] < 3e-7 and r["frac_5e2"] < FORKED, (pipeline, r)
         assert st.camera_rays == cnt["camera_rays"]
 
 
@@ -807,7 +815,7 @@ def test_render_from_a_scene_file_matches_the_oracle_reading_the_same_file(devic
     gpu = device.film(1.0 / cam.effective_spp)
     film, _, cnt = orc.render(osb, ocam, mode=mode, seed=1)
     r = helpers.compare_same_stream(gpu, film / cam.effective_spp)
-    assert r["median_rel"] < 1e-4 and r["frac_5e2"] < 0.08, r
+    assert r["median_rel"] < 9e-8 and r["frac_5e2"] < FORKED, r
     assert st.camera_rays == cnt["camera_rays"]
     # the committed full-size files load and render too (a few strata of the Cornell box)
     root = Path(ra.__file__).resolve().parent.parent / "scenes"
@@ -839,7 +847,7 @@ def test_edge_sizes(device, pipeline):
         gpu = device.film(1.0 / c.effective_spp)
         assert gpu.shape == (h, w, 3) and np.isfinite(gpu).all()
         r = helpers.compare_same_stream(gpu, film / c.effective_spp)
-        assert r["frac_5e2"] <= 0.1 + 2.0 / (w * h), (w, h, spp, r)  # a forked path is a whole pixel of a tiny image
+        assert r["frac_5e2"] <= FORKED + 1.0 / (w * h), (w, h, spp, r)  # none measured; a forked path is a whole pixel of a tiny image
         assert device.film_rgb8(1.0 / c.effective_spp).shape == (h, w, 3)
     # an empty stratum range renders nothing and leaves the film alone
     device.film_resize(8, 8)
