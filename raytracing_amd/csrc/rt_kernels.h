@@ -343,6 +343,12 @@ __device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, f
         // t ~ 0 root through its 0.001 lower bound, which fp32 at scene scale cannot resolve
         if (r == origin_ref) return;
         h = hit_quad<UNIFORM>(sc.quads + 6 * idx, o, d, tlo, best.t, t, a, b);
+        // Two quads met at exactly the same t (coincident faces): the reference keeps the one it
+        // visits later -- HittableVec::hit and BVHNode::hit both accept t <= closest
+        // (hittable.rs:252-264, boundingbox.rs:219-231) and walk left to right.  Quads are stored
+        // in that visiting order, so the larger index wins whatever order a tree search takes.
+        // (A sphere never takes a tie from a quad: its root must lie strictly inside the interval.)
+        if (h && t == best.t && (best.ref >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD && best.ref > r) h = false;
     } else if (kind == RT_KIND_SPHERE) {
         h = hit_sphere<UNIFORM>(sc.spheres + 3 * idx, o, d, time, tlo, best.t, r == origin_ref, t);
     } else {

@@ -956,3 +956,145 @@ def test_native_binary_writes_the_same_bytes_as_the_python_route(device, tmp_pat
     assert tok[:4] == ["P3", "48", "48", "255"]
     got = np.array(tok[4:], dtype=np.uint8).reshape(48, 48, 3)
     assert np.array_equal(got, want)
+
+
+DISC_TOML = '''
+[textures.tiles]
+type = "Checkerboard"
+scale = 0.7
+textures = ["#d0d0d0", "#306030"]
+
+[materials.grey]
+type = "SolidColor"
+color = 0xB0B0B0
+
+[materials.tiled]
+type = "Lambertian"
+texture = "tiles"
+
+[materials.blue]
+type = "SolidColor"
+color = 0x3050C0
+
+[materials.lamp]
+type = "ColoredLight"
+color = 0xfff
+brightness = 8
+
+[[objects]]
+type = "Parallelogram"
+corner = [-6, 0, -6]
+vectors = [[12, 0, 0], [0, 0, 12]]
+material = "grey"
+
+[[objects]]
+type = "Disc"
+center = [-1.5, 1.0, 0.0]
+vectors = [[1.2, 0.3, 0.0], [0.0, 0.4, 1.0]]
+material = "tiled"
+
+[[objects]]
+type = "Triangle"
+points = [[1.0, 0.2, -1.0], [3.5, 0.4, 0.5], [1.5, 2.5, 0.8]]
+material = "blue"
+'''
+
+
+def _disc_world(sb, toml_list, behind_bvh):
+    """A Disc given by its centre (Disc::from_center, hittable.rs:596-619, through the scene file), a
+    Triangle, a Disc given by its corner, and a Triangle on the very same corner and edge vectors as
+    that Disc (same plane, same t to the bit: the later one wins where they overlap,
+    hittable.rs:252-264), over a floor and under a lamp."""
+    objs = [toml_list]  # a nested HittableVec: the file's three objects
+    red = sb.lambertian(sb.tex_solid(0.8, 0.25, 0.2))
+    gold = sb.metal((0.9, 0.7, 0.3), 0.05)
+    q, u, v = (0.5, 0.6, -3.0), (2.0, 0.5, 0.0), (0.0, 1.5, 0.6)
+    objs.append(sb.quad(q, u, v, red, shape=ra.SHAPE_DISC))
+    objs.append(sb.quad(q, u, v, gold, shape=ra.SHAPE_TRIANGLE))
+    lamp = sb.quad((-1.5, 5.0, -1.5), (3, 0, 0), (0, 0, 3), sb.light(sb.tex_solid(8, 8, 8)))
+    objs.append(lamp)
+    sb.set_world(sb.list([sb.bvh(objs)]) if behind_bvh else sb.list(objs))
+    sb.set_lights(lamp)
+    return (q, u, v), len(objs)
+
+
+@pytest.mark.parametrize("behind_bvh", [False, True], ids=["flat-list", "behind-a-bvh"])
+def test_disc_and_triangle_on_the_device(device, behind_bvh):
+    """RT_SHAPE_DISC and RT_SHAPE_TRIANGLE against the oracle (hittable.rs:509-517, 627-638), in a
+    flat world (the scan's general loop) and behind a BVH (4-wide and binary): a fixed ray batch,
+    rays aimed just inside and just outside the disc's rim and the triangle's edges, the tie rule
+    of coincident shapes, and same-stream renders through every pipeline."""
+    from oracle import config_oracle
+    host, osb = ra.SceneBuilder(), orc.scene()
+    # the product reads the file with its own loader (Disc::from_center in C++), the oracle through the
+    # independent reader, which forms corner and doubled vectors itself
+    (q, u, v), n_objs = _disc_world(host, host.load_toml(DISC_TOML), behind_bvh)
+    _disc_world(osb, osb.list(config_oracle.toml_objects(osb, DISC_TOML)), behind_bvh)
+    assert n_objs == 4 and host.prim_count() == osb.prim_count() == 6
+    desc = device.upload(host)
+    shapes = sorted(desc.quads[i].shape for i in range(desc.n_quads))
+    assert shapes.count(ra.SHAPE_DISC) >= 2 and shapes.count(ra.SHAPE_TRIANGLE) >= 2
+    cam = ra.CameraSettings(image_width=72, image_height=48, samples_per_px=16, max_depth=8, vfov=50.0, background=(0.03, 0.03, 0.05),
+                            camera_center=(0.5, 3.0, 8.0), camera_target=(0.3, 0.8, -0.5))
+    q, u, v = (np.array(x, np.float64) for x in (q, u, v))
+    rng = np.random.default_rng(8)
+
+    def aimed(points):
+        o = np.tile(np.array([[0.4, 3.5, 6.0]]), (len(points), 1))
+        return o.astype(np.float32), (points - o).astype(np.float32)
+
+    # rim of the corner-form disc: (alpha - .5)^2 + (beta - .5)^2 = .25 (1 +- 2e-3)^2; the triangle shares its plane
+    ang = rng.random(4000) * 2 * np.pi
+    rad = 0.5 * np.where(np.arange(4000) % 2 == 0, 1.0 - 2e-3, 1.0 + 2e-3)
+    al, be = 0.5 + rad * np.cos(ang), 0.5 + rad * np.sin(ang)
+    rim_o, rim_d = aimed(q + al[:, None] * u + be[:, None] * v)
+    # the triangle's hypotenuse alpha + beta = 1 -+ 2e-3 and its legs alpha, beta = +-2e-3, off the disc
+    s = rng.random(3000)
+    off = np.where(np.arange(3000) % 2 == 0, -2e-3, 2e-3)
+    tri_pts = np.concatenate([q + (s[:1000] * (1 + off[:1000]))[:, None] * u + ((1 - s[:1000]) * (1 + off[:1000]))[:, None] * v,
+                              q + off[1000:2000, None] * u + (0.02 + 0.1 * s[1000:2000])[:, None] * v,
+                              q + (0.02 + 0.1 * s[2000:])[:, None] * u + off[2000:, None] * v])
+    tri_o, tri_d = aimed(tri_pts)
+    o = np.concatenate([rim_o, tri_o])
+    dd = np.concatenate([rim_d, tri_d])
+    tm = np.zeros(len(o), np.float32)
+    accels = [("auto", 4)] if not behind_bvh else [("reference", 4), ("sah", 4), ("reference", 2)]
+    try:
+        for builder, width in accels:
+            device.set_accel(builder, width)
+            device.upload(host)
+            assert device.accel_info()["kind"] == ("flat" if not behind_bvh else ("bvh4" if width == 4 else "bvh2"))
+            r = helpers.check_intersection_parity(device, host, osb, cam, ((-4, 0, -4), (4, 3, 4)), 10.0, name="disc", n=32768, seed=21)
+            hit, prim, t, uu, vv = device.intersect_batch(o, dd, tm)
+            h2, p2, t2, u2, v2, second = orc.intersect_batch(osb, o, dd, tm)
+            same = (hit == h2) & (prim == p2)
+            with np.errstate(invalid="ignore"):
+                tie = (h2 == 1) & (np.abs(second - t2) <= 1e-12 * np.abs(t2))
+            # coincident shapes: list order decides ties, as in HittableVec::hit; behind a tree the device
+            # keeps the quad the reference's left-to-right walk visits later, whatever order it searches in
+            assert same.mean() > 0.999, (builder, width, (~same).sum())
+            assert tie.sum() > 100  # the overlap of the coincident disc and triangle was met
+            # both sides of the rim were met (other objects hide part of it from the rays' origin):
+            # inside rays hit the disc or the triangle sharing its plane, outside rays never the disc
+            disc_id, tri_id = 3, 4  # creation order: floor 0, disc 1, triangle 2, disc 3, triangle 4, lamp 5
+            inside = np.arange(4000) % 2 == 0
+            got_shape = np.isin(p2[:4000], (disc_id, tri_id))
+            assert got_shape[inside].mean() > 0.8 and (p2[:4000][inside] == disc_id).mean() > 0.3 and not (p2[:4000][~inside] == disc_id).any()
+            ok = same & (hit == 1)
+            assert np.abs(uu[ok] - u2[ok]).max() < 1e-4 and np.abs(vv[ok] - v2[ok]).max() < 1e-4
+        device.set_accel("auto", 4)
+        device.upload(host)
+        device.film_resize(cam.image_width, cam.image_height)
+        film, _, cnt = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=6)
+        for pipeline, kw in PIPELINES.items():
+            if behind_bvh and pipeline in ("lane-bound", "regrouped"):
+                continue
+            device.film_clear()
+            st = device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=6, **kw)
+            rr = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
+            assert rr["median_rel"] < 1e-6 and rr["frac_5e2"] < 2e-3, (pipeline, rr)
+            assert st.camera_rays == cnt["camera_rays"]
+            want = cnt["segments"] - cnt["zero_weight_segments"]
+            assert abs(st.segments - want) <= 5e-3 * want + 5, (pipeline, st.segments, want)
+    finally:
+        device.set_accel("auto", 4)
