@@ -3,6 +3,9 @@
 * new_cornell_blockmeans.npy comes from the reference's own output image
   assets/new-cornell.png (600x600 linear PNG written by its PngWriter): 20x20 block means of
   the 8-bit values / 255.  Needs /root/reference; skipped when it is absent.
+* diary_blockmeans.npz: block means (8-bit values / 255) of four more images the reference holds --
+  assets/earth.png, glass.png (400x225, 9x16 blocks), cornell-3.png, cornell-4.png (600x600, 20x20
+  blocks) -- for the pins in tests/test_oracle_kats.py.  Needs /root/reference; skipped when absent.
 * the rest are outputs of the CPU oracle (oracle/liboracle.so) on fixed seeds.
 * c?_oracle_64x64_converged.npz: the 64x64 frame at 16384 spp (128^2 strata), plus the oracle's
   own RMSE against it at 256 spp for three seeds of the device's generator (so a device render
@@ -30,6 +33,17 @@ def main():
         a = np.asarray(Image.open(ref_png)).astype(np.float64) / 255.0
         bm = a.reshape(20, 30, 20, 30, 3).mean(axis=(1, 3)).astype(np.float32)
         np.save(HERE / "new_cornell_blockmeans.npy", bm)
+    assets = Path("/root/reference/assets")
+    if assets.exists():
+        from PIL import Image
+        import diary_scenes
+        out = {}
+        for name, (_, _, (rows, cols)) in diary_scenes.DIARY.items():
+            a = np.asarray(Image.open(assets / f"{name}.png").convert("RGB")).astype(np.float64) / 255.0
+            out[name] = diary_scenes.block_means(a, rows, cols).astype(np.float32)
+        np.savez_compressed(HERE / "diary_blockmeans.npz", **out)
+    if "--images-only" in sys.argv:
+        return
     for name, fn, mode in (("c1", ra.scenes.cornell_main, orc.MODE_REF_EXACT), ("c3", ra.scenes.cornell_book3, orc.MODE_BOOK3)):
         host, osb, cam = helpers.build_both(fn, width=64, spp=16)
         film, _, cnt = orc.render(osb, cam, mode=mode, seed=1)
