@@ -104,3 +104,26 @@ def test_full_resolution_render_properties(device, name):
 # The Book-2 scene is lit by a small lamp through long paths: its block means are the noisiest.
 SMALL = {"c2": (80, 45, 5), "c4": (64, 64, 8), "c5": (128, 72, 8)}
 BLOCK_BOUNDS = {"c2": (0.995, 0.02), "c4": (0.9, 0.15), "c5": (0.99, 0.03)}
+
+
+@pytest.mark.parametrize("name", ["earth", "glass", "cornell-3", "cornell-4"])
+def test_device_render_against_the_reference_held_images(device, name):
+    """End to end against files the reference itself holds: the device's render of the scenes behind
+    assets/earth.png, glass.png, cornell-3.png and cornell-4.png (tests/diary_scenes.py), through its
+    own 8-bit output stage, against the block means of those images.  Same bounds as the oracle's
+    pins in tests/test_oracle_kats.py."""
+    import diary_scenes
+    from test_oracle_kats import DIARY_BOUNDS, GOLD
+    fn, kw, (rows, cols) = diary_scenes.DIARY[name]
+    want = np.load(GOLD / "diary_blockmeans.npz")[name].astype(np.float64)
+    host = ra.SceneBuilder()
+    cam, gamma = fn(host, **kw)
+    device.upload(host)
+    device.film_resize(cam.image_width, cam.image_height)
+    device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=1)
+    img = device.film_rgb8(1.0 / cam.effective_spp, gamma=gamma).astype(np.float64) / 255.0
+    got = diary_scenes.block_means(img, rows, cols)
+    corr, lo, hi = DIARY_BOUNDS[name]
+    c = float(np.corrcoef(got.ravel(), want.ravel())[0, 1])
+    print(name, "corr", c, "mean ratio", got.mean() / want.mean())
+    assert c > corr and lo < got.mean() / want.mean() < hi, (c, got.mean() / want.mean())
