@@ -20,7 +20,7 @@ MAIN = bin/rt_main
 
 all: $(LIB) $(MAIN) oracle sanitize
 
-$(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h include/rt_amd.h
+$(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h raytracing_amd/csrc/rt_leafword.h include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 raytracing_amd/host/%.o: raytracing_amd/host/%.cpp raytracing_amd/host/raytracing.hpp include/rt_amd.h
@@ -45,7 +45,7 @@ bin/host_sanitize: $(SAN_SRC) raytracing_amd/host/raytracing.hpp raytracing_amd/
 # the same library with per-step counters in the regrouping kernel (tools/regroup_steps.py)
 STATS_LIB = raytracing_amd/librt_amd_stats.so
 stats-lib: $(STATS_LIB)
-$(STATS_LIB): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h include/rt_amd.h $(HOST_OBJ)
+$(STATS_LIB): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h raytracing_amd/csrc/rt_leafword.h include/rt_amd.h $(HOST_OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_REGROUP_STATS -c $< -o raytracing_amd/csrc/rt_device_stats.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ raytracing_amd/csrc/rt_device_stats.o $(HOST_OBJ) -lz
 

@@ -56,7 +56,9 @@ SHADE_WRITE_BYTES = 56           # a surviving ray's records
 FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path deposits radiance
 # algorithmic flops per segment measured by the oracle's counters (flops_per_segment below) on
 # the full workloads; used when the CPU leg is skipped, recomputed when it runs
-FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0}
+# (c2, c4, c5: full scene content, a few strata of the full frame, the reference's own binary BVH
+# walked left child first -- 40.9, 15.7 and 340.7 box tests per segment)
+FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0, "c2": 1310.7, "c4": 1248.7, "c5": 9525.6}
 # HBM-side bytes per segment of the persistent kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
 # WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments), keyed by
 # (workload, regrouping variant): profiles/r1h_pmc_c3_spp64_regroup.txt and

@@ -167,13 +167,14 @@ typedef struct {
 #define RT_FLAG_TIME_KERNELS 1u /* bracket kernels with HIP events (see rt_stats) */
 #define RT_FLAG_WAVEFRONT 2u    /* ray-queue pipeline (scan/generate/extend/shade launches) instead of
                                  * the persistent path kernel; same image for the same seed */
-/* Persistent kernel on a flat world (one list of primitives): either every lane carries one path
- * from its camera ray to its end, or every wave keeps a pool of paths in LDS and regroups them
- * by the step they wait for (closest hit, scatter at a diffuse / metal / glass vertex, end), so
- * that each step runs with most lanes active.  Same image either way.  Default: regrouping
- * (measured 40 % faster on the Book-3 Cornell box, 3 % on the main.rs scene, whose paths are
- * about two segments long and scatter one way).  RT_FLAG_NO_REGROUP takes the lane-bound
- * kernel; RT_FLAG_REGROUP is the default spelled out.
+/* The persistent kernel has two variants.  Lane-bound: every lane carries one path from its camera
+ * ray to its end.  Regrouping: every wave keeps a pool of paths in LDS and regroups them by the step
+ * they wait for (closest hit, scatter at a diffuse / metal / glass vertex, end), so that each step runs
+ * with most lanes active; behind a tree a lane keeps a traversal across turns and takes the next ray
+ * from the pool when it is done.  Same image either way.  Default: regrouping on a flat world
+ * (measured 40 % faster on the Book-3 Cornell box, 3 % on the main.rs scene) and behind trees of 8192
+ * nodes or more (14 % faster on the 1 M-primitive scene, 2 % slower on the Book-1 scene's 232 nodes);
+ * RT_FLAG_REGROUP asks for regrouping wherever it exists, RT_FLAG_NO_REGROUP for the lane-bound kernel.
  * Regrouping needs max_depth <= 255 and falls back otherwise. */
 #define RT_FLAG_REGROUP 4u
 #define RT_FLAG_NO_REGROUP 8u
@@ -230,6 +231,12 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *scene);
 #define RT_BUILD_REFERENCE 0u
 #define RT_BUILD_SAH 1u
 #define RT_BUILD_AUTO 2u /* both, keep the lower surface-area cost */
+/* Or-ed into the builder: the size of a 4-wide node.  128 bytes with fp32 child boxes, or 64 bytes
+ * whose child boxes are bytes on a grid of the node's own, rounded outward -- the same tree and the
+ * same hits, half the bytes and four loads instead of seven per visit, a little more arithmetic.
+ * With neither flag the upload picks by the size of the tree (byte boxes from 8192 nodes). */
+#define RT_BUILD_FP32_BOXES 0x100u
+#define RT_BUILD_BYTE_BOXES 0x200u
 int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width);
 typedef struct {
     uint32_t kind;          /* 0 = flat list scan, 1 = binary nodes, 2 = 4-wide nodes */
@@ -241,7 +248,7 @@ typedef struct {
                              * rectangular box (box3, hittable.rs:398-455) and take one slab test each */
     uint32_t flat_alone_spheres; /* flat only: spheres that no other primitive of the list reaches into; the
                              * regrouping kernel knows where a ray going into one of them ends */
-    uint32_t pad;
+    uint32_t node_bytes;    /* size of a node of the structure searched (wide: 64 quantised, 128 fp32 boxes) */
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 /* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it

@@ -86,10 +86,11 @@ RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
 
 class RtAccelInfo(C.Structure):
     _fields_ = [("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32), ("cost", f64),
-                ("flat_quads", u32), ("flat_boxes", u32), ("flat_alone_spheres", u32), ("pad", u32)]
+                ("flat_quads", u32), ("flat_boxes", u32), ("flat_alone_spheres", u32), ("node_bytes", u32)]
 
 
 RT_BUILD_REFERENCE, RT_BUILD_SAH, RT_BUILD_AUTO = 0, 1, 2
+RT_BUILD_FP32_BOXES, RT_BUILD_BYTE_BOXES = 0x100, 0x200
 RT_FLAG_TIME_KERNELS = 1
 RT_FLAG_WAVEFRONT = 2
 RT_FLAG_REGROUP = 4

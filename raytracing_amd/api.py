@@ -273,16 +273,20 @@ class Device:
     def set_stream(self, hip_stream_ptr):
         self._check(self.lib.rt_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "rt_set_stream")
 
-    def set_accel(self, builder="auto", width=4):
-        """Structure built by the next upload: builder "reference" | "sah" | "auto", width 2 | 4."""
+    def set_accel(self, builder="auto", width=4, fp32_boxes=None):
+        """Structure built by the next upload: builder "reference" | "sah" | "auto", width 2 | 4;
+        fp32_boxes: True = 128-byte wide nodes with fp32 child boxes, False = 64-byte nodes with byte
+        boxes, None = chosen by the size of the tree."""
         b = {"reference": _ffi.RT_BUILD_REFERENCE, "sah": _ffi.RT_BUILD_SAH, "auto": _ffi.RT_BUILD_AUTO}[builder]
+        if fp32_boxes is not None:
+            b |= _ffi.RT_BUILD_FP32_BOXES if fp32_boxes else _ffi.RT_BUILD_BYTE_BOXES
         self._check(self.lib.rt_set_accel(self.h, b, width), "rt_set_accel")
 
     def accel_info(self):
         a = _ffi.RtAccelInfo()
         self._check(self.lib.rt_get_accel_info(self.h, C.byref(a)), "rt_get_accel_info")
         return dict(kind=("flat", "bvh2", "bvh4")[a.kind], nodes=a.nodes, depth=a.depth, stack_entries=a.stack_entries, cost=a.cost,
-                    flat_quads=a.flat_quads, flat_boxes=a.flat_boxes, flat_alone_spheres=a.flat_alone_spheres)
+                    flat_quads=a.flat_quads, flat_boxes=a.flat_boxes, flat_alone_spheres=a.flat_alone_spheres, node_bytes=a.node_bytes)
 
     def upload(self, scene: SceneBuilder):
         desc = scene.flatten()

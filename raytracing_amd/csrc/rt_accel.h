@@ -14,6 +14,7 @@
 // Nodes are numbered breadth first.
 #pragma once
 #include "../../include/rt_amd.h"
+#include "rt_leafword.h"
 
 #include <algorithm>
 #include <cmath>
@@ -35,6 +36,20 @@ struct Node4 {
     uint32_t pad[4];
 };
 static_assert(sizeof(Node4) == 128, "wide node is one 128-byte line");
+
+// The same node in 64 bytes: child boxes as bytes on a grid of the node's own.  Per axis
+// plane = origin + q * 2^(exp - 127); lower planes are rounded down and upper planes up, after
+// widening the box by a few fp32 ulps of the node's coordinates (the device evaluates
+// q * (s / d) + (origin - o) / d in fp32), so a quantised box always contains the fp32 one.
+struct Node4Q {
+    float origin[3];
+    uint32_t exps;      // biased exponents of the grid steps: x | y << 8 | z << 16
+    uint32_t lo[3];     // one byte per child
+    uint32_t hi[3];
+    uint32_t spare[2];
+    uint32_t child[4];
+};
+static_assert(sizeof(Node4Q) == 64, "quantised wide node is half a 128-byte line");
 
 namespace accel {
 
@@ -97,6 +112,16 @@ struct Builder {
     std::string error;
 
     explicit Builder(const rt_scene_desc *scene) : s(scene), node_slot(scene->n_nodes, -1) {}
+
+    // reference -> reference with the class of its material (see RT4_CLASS_SHIFT)
+    uint32_t with_class(uint32_t ref) const {
+        const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
+        const uint32_t mat = kind == RT_KIND_QUAD ? s->quads[idx].mat : kind == RT_KIND_SPHERE ? s->spheres[idx].mat : s->media[idx].mat;
+        const uint32_t type = s->materials[mat].type;
+        const uint32_t cls = type == RT_MAT_LIGHT ? RT4_CLASS_END : type == RT_MAT_METAL ? RT4_CLASS_METAL
+                                                                 : type == RT_MAT_DIELECTRIC ? RT4_CLASS_GLASS : RT4_CLASS_DIFFUSE;
+        return ref | (cls << RT4_CLASS_SHIFT);
+    }
 
     Box prim_box(uint32_t ref) const {
         const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
@@ -269,7 +294,7 @@ struct Builder {
             // a world of one primitive: one node holding it
             Node4 n;
             fill_empty(n);
-            set_child(n, 0, slots[root].ref, slots[root].box);
+            set_child(n, 0, with_class(slots[root].ref), slots[root].box);
             nodes.push_back(n);
             st.nodes = 1, st.depth = 1, st.stack_need = 1, st.leaves = 1;
             return (RT_KIND_NODE << RT_REF_KIND_SHIFT) | 0u;
@@ -299,7 +324,7 @@ struct Builder {
             for (int i = 0; i < n; ++i) {
                 const Slot &c = slots[ch[i]];
                 if (c.node < 0) {
-                    set_child(nd, i, c.ref, c.box);
+                    set_child(nd, i, with_class(c.ref), c.box);
                     ++st.leaves;
                 } else {
                     set_child(nd, i, (RT_KIND_NODE << RT_REF_KIND_SHIFT) | next_index, c.box);
@@ -373,6 +398,8 @@ inline double sa_cost(const std::vector<Node4> &nodes) {
 // and keeps the one with the lower surface-area cost.  Returns "" or an error.
 inline std::string build_wide_bvh(const rt_scene_desc *s, uint32_t builder, std::vector<Node4> &nodes, uint32_t &root,
                                   Stats &st) {
+    if (s->n_quads >= (1u << RT4_CLASS_SHIFT) || s->n_spheres >= (1u << RT4_CLASS_SHIFT) || s->n_media >= (1u << RT4_CLASS_SHIFT))
+        return "more than 2^27 primitives of one kind";
     Builder b(s);
     b.slots.reserve(size_t(s->n_quads + s->n_spheres + s->n_media) * 2 + 16);
     const int32_t top = b.from_ref(s->root, 0);
@@ -395,6 +422,62 @@ inline std::string build_wide_bvh(const rt_scene_desc *s, uint32_t builder, std:
     } else if (builder == RT_BUILD_SAH) {
         finish(top, nodes, st);
     }
+    return "";
+}
+
+// 128-byte nodes -> 64-byte nodes (same tree, same numbering).
+inline void quantise_nodes(const std::vector<Node4> &nodes, std::vector<Node4Q> &out) {
+    out.assign(nodes.size(), Node4Q{});
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const Node4 &n = nodes[i];
+        Node4Q &q = out[i];
+        for (int k = 0; k < 4; ++k) q.child[k] = n.child[k];
+        for (int a = 0; a < 3; ++a) {
+            double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+            for (int k = 0; k < 4; ++k)
+                if (n.child[k] != RT_REF_NONE) lo = std::min(lo, double(n.lo[a][k])), hi = std::max(hi, double(n.hi[a][k]));
+            if (!(lo <= hi)) lo = hi = 0.0; // a node without children (never built)
+            // what fp32 rounding can move a plane by on the device, with room to spare
+            const double margin = 8.0 * std::ldexp(std::max(std::fabs(lo), std::fabs(hi)), -23) + 1e-30;
+            const float origin = std::nextafter(float(lo - margin), -std::numeric_limits<float>::infinity());
+            const double extent = (hi + margin) - double(origin);
+            int e = int(std::ceil(std::log2(std::max(extent, 1e-30) / 255.0)));
+            while (std::ldexp(255.0, e) < extent) ++e; // log2 rounding
+            e = std::min(std::max(e, -100), 100);
+            const double step = std::ldexp(1.0, e);
+            q.origin[a] = origin;
+            q.exps |= uint32_t(e + 127) << (8 * a);
+            for (int k = 0; k < 4; ++k) {
+                uint32_t ql = 255u, qh = 0u; // an unused slot: inverted, and its ref says so too
+                if (n.child[k] != RT_REF_NONE) {
+                    const double l = std::floor((double(n.lo[a][k]) - margin - double(origin)) / step);
+                    const double h = std::ceil((double(n.hi[a][k]) + margin - double(origin)) / step);
+                    ql = uint32_t(std::min(std::max(l, 0.0), 255.0));
+                    qh = uint32_t(std::min(std::max(h, 0.0), 255.0));
+                }
+                q.lo[a] |= ql << (8 * k);
+                q.hi[a] |= qh << (8 * k);
+            }
+        }
+    }
+}
+
+// Every quantised child box contains the fp32 one (with the rounding margin).  Returns "" or what is wrong.
+inline std::string verify_quantised(const std::vector<Node4> &nodes, const std::vector<Node4Q> &q) {
+    if (nodes.size() != q.size()) return "quantised node count differs";
+    for (size_t i = 0; i < nodes.size(); ++i)
+        for (int k = 0; k < 4; ++k) {
+            if (q[i].child[k] != nodes[i].child[k]) return "quantised child refs differ";
+            if (nodes[i].child[k] == RT_REF_NONE) continue;
+            for (int a = 0; a < 3; ++a) {
+                const double step = std::ldexp(1.0, int((q[i].exps >> (8 * a)) & 0xFFu) - 127);
+                const double lo = double(q[i].origin[a]) + step * double((q[i].lo[a] >> (8 * k)) & 0xFFu);
+                const double hi = double(q[i].origin[a]) + step * double((q[i].hi[a] >> (8 * k)) & 0xFFu);
+                const double ulp = std::ldexp(std::max(std::fabs(double(nodes[i].lo[a][k])), std::fabs(double(nodes[i].hi[a][k]))), -23);
+                if (!(lo <= double(nodes[i].lo[a][k]) - 4.0 * ulp && hi >= double(nodes[i].hi[a][k]) + 4.0 * ulp))
+                    return "quantised box does not contain the fp32 box";
+            }
+        }
     return "";
 }
 
@@ -436,8 +519,9 @@ inline std::string verify_wide_bvh(const rt_scene_desc *s, const std::vector<Nod
                 if (j <= i || j >= nodes.size()) return "child index does not point forward";
                 content = below[j];
             } else {
-                content = b.prim_box(c);
-                got.push_back(c);
+                if (c != b.with_class(c & ~RT4_CLASS_MASK)) return "leaf does not carry the class of its material";
+                content = b.prim_box(c & ~RT4_CLASS_MASK);
+                got.push_back(c & ~RT4_CLASS_MASK);
             }
             for (int a = 0; a < 3; ++a)
                 if (!(stored.lo[a] <= content.lo[a] && stored.hi[a] >= content.hi[a])) return "child box does not contain its content";

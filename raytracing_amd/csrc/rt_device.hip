@@ -40,7 +40,10 @@ struct rt_handle {
     uint32_t build = RT_BUILD_AUTO, width = 4; // rt_set_accel: applies to the next upload
     uint32_t stack4 = 0;                    // LDS stack entries per lane of the wide traversal
     uint32_t lds_nodes4 = 0;                // wide nodes staged in LDS behind the stack
-    size_t dyn_lds4() const { return size_t(stack4) * BLOCK * sizeof(uint32_t) + size_t(lds_nodes4) * sizeof(Node4); }
+    size_t node4_bytes() const { return accel == ACCEL_BVH4Q ? sizeof(Node4Q) : sizeof(Node4); }
+    size_t dyn_lds4() const { return size_t(stack4) * BLOCK * sizeof(uint32_t) + size_t(lds_nodes4) * node4_bytes(); }
+    enum { BOXES_AUTO = 0, BOXES_FP32 = 1, BOXES_BYTE = 2 };
+    int boxes = BOXES_AUTO;                 // rt_set_accel: RT_BUILD_FP32_BOXES / RT_BUILD_BYTE_BOXES
     accel::Stats accel_stats{};
     uint32_t has_media = 0, n_prims = 0, alone_spheres = 0, n_quads = 0, n_spheres = 0, n_materials = 0;
     bool has_specular = false;
@@ -62,6 +65,9 @@ struct rt_handle {
     // quantize, the parity hooks): one buffer kept on the handle, grown when a call needs more
     void *stage = nullptr;
     size_t stage_bytes = 0;
+    // global-memory part of the traversal stacks of k_paths_pool (entries beyond POOL_STACK)
+    uint32_t *spill = nullptr;
+    size_t spill_bytes = 0;
     // this device's copy of `scratch` (below): rt_film_quantize_noalloc
     uint32_t *noalloc_scratch = nullptr;
 
@@ -254,6 +260,31 @@ int validate_scene(rt_handle *h, const rt_scene_desc *s) {
             return fail(h, "rt_upload_scene: a quad light must be a parallelogram");
     }
     return 0;
+}
+
+// Stack entries the binary traversal (traverse) can need for this descriptor, whatever the caller
+// says in max_stack: an interior node pushes its far child and goes on with the near one; a list
+// pushes every entry that is a node and then pops them from the top.  Children point forward
+// (validated), so one backward pass does it.
+uint32_t binary_stack_need(const rt_scene_desc *s) {
+    std::vector<uint32_t> need(s->n_nodes, 0);
+    auto of = [&](uint32_t ref) { return (ref >> RT_REF_KIND_SHIFT) == RT_KIND_NODE ? need[ref & RT_REF_INDEX_MASK] : 0u; };
+    for (uint32_t i = s->n_nodes; i-- > 0;) {
+        const rt_node &n = s->nodes[i];
+        if (n.right != RT_NODE_LEAF) {
+            need[i] = 1u + std::max(of(n.left), of(n.right));
+        } else {
+            uint32_t pushed = 0, worst = 0;
+            for (uint32_t k = 0; k < n.count; ++k) {
+                const uint32_t r = s->refs[n.left + k];
+                if ((r >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) continue;
+                worst = std::max(worst, pushed + need[r & RT_REF_INDEX_MASK]); // entries below it are still on the stack
+                ++pushed;
+            }
+            need[i] = std::max(worst, pushed);
+        }
+    }
+    return of(s->root);
 }
 
 int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCamera *out, uint32_t *se) {
@@ -502,7 +533,7 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
                  unsigned long long total) {
     auto kernel = k_paths<MODE, ACCEL>;
     int per_cu = 0, n_cu = 0;
-    const size_t dyn_lds = ACCEL == ACCEL_BVH4 ? h->dyn_lds4() : 0;
+    const size_t dyn_lds = accel_is_wide(ACCEL) ? h->dyn_lds4() : 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
@@ -550,6 +581,44 @@ int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &fi
     return 0;
 }
 
+// The regrouping kernel behind the wide BVH: a pool of paths per wave, traversals resumable per lane.
+constexpr uint32_t POOL_MIN_NODES = 8192; // trees from this size take it by default
+template <int MODE, bool QUANT>
+int launch_paths_pool(rt_handle *h, const rt_render_params *p, const Film &film, unsigned long long total) {
+    auto kernel = k_paths_pool<MODE, QUANT>;
+    // what is left of a quarter of the CU's LDS behind pools and stacks holds the top of the tree
+    const size_t node_bytes = QUANT ? sizeof(Node4Q) : sizeof(Node4), budget = 40 * 1024;
+    const uint32_t lds_nodes = POOL_LDS_FIXED < budget ? uint32_t(std::min<size_t>(h->accel_stats.nodes, (budget - POOL_LDS_FIXED) / node_bytes)) : 0u;
+    const size_t dyn_lds = POOL_LDS_FIXED + lds_nodes * node_bytes;
+    int per_cu = 0, n_cu = 0;
+    RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));
+    RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
+    if (p->waves_per_simd && int(p->waves_per_simd) < per_cu) per_cu = int(p->waves_per_simd);
+    const unsigned long long per_block = (unsigned long long)POOL_SLOTS * (BLOCK / WAVE);
+    unsigned long long blocks = (unsigned long long)per_cu * n_cu;
+    blocks = std::min(blocks, (total + per_block - 1) / per_block);
+    // stack entries beyond the LDS part: one column per lane of the grid
+    const uint32_t deep = h->accel_stats.stack_need > POOL_STACK ? h->accel_stats.stack_need - POOL_STACK : 0u;
+    const size_t need = size_t(blocks) * BLOCK * deep * sizeof(uint32_t);
+    if (need > h->spill_bytes) {
+        RT_HIP(hipStreamSynchronize(h->stream));
+        if (h->spill) (void)hipFree(h->spill);
+        h->spill = nullptr, h->spill_bytes = 0;
+        RT_HIP(hipMalloc((void **)&h->spill, need));
+        h->spill_bytes = need;
+    }
+    Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
+    int e = tm.begin(4);
+    kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), dyn_lds, h->stream>>>(h->d_sc, h->d_cam, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
+                                                                       h->d_ctrl, h->has_media, 1024u, h->spill, lds_nodes);
+    tm.end(e);
+    RT_HIP(hipGetLastError());
+    h->stats.launches[4]++;
+    h->stats.regrouped = 1;
+    return 0;
+}
+
 int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
                       unsigned long long total) {
     RT_HIP(hipEventRecord(h->ev_begin, h->stream));
@@ -564,10 +633,19 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
             rc = tables ? launch_paths_regroup<RT_MODE_REF_EXACT, true>(h, p, film, total) : launch_paths_regroup<RT_MODE_REF_EXACT, false>(h, p, film, total);
         else
             rc = tables ? launch_paths_regroup<RT_MODE_BOOK3, true>(h, p, film, total) : launch_paths_regroup<RT_MODE_BOOK3, false>(h, p, film, total);
+    } else if (accel_is_wide(h->accel) && regroup_fits &&
+               ((p->flags & RT_FLAG_REGROUP) || (regroup_wanted && h->accel_stats.nodes >= POOL_MIN_NODES))) {
+        // behind a tree the pool of paths per wave pays where traversals are long (measured: +14 % at 466 k
+        // nodes, -2 % at 232); RT_FLAG_REGROUP asks for it on any tree
+        if (p->mode == RT_MODE_REF_EXACT)
+            rc = h->accel == ACCEL_BVH4Q ? launch_paths_pool<RT_MODE_REF_EXACT, true>(h, p, film, total) : launch_paths_pool<RT_MODE_REF_EXACT, false>(h, p, film, total);
+        else
+            rc = h->accel == ACCEL_BVH4Q ? launch_paths_pool<RT_MODE_BOOK3, true>(h, p, film, total) : launch_paths_pool<RT_MODE_BOOK3, false>(h, p, film, total);
     } else {
 #define RT_PATHS(MODE)                                                                                    \
     (h->accel == ACCEL_FLAT   ? launch_paths<MODE, ACCEL_FLAT>(h, dc, p, film, total)                        \
      : h->accel == ACCEL_BVH4 ? launch_paths<MODE, ACCEL_BVH4>(h, dc, p, film, total)                        \
+     : h->accel == ACCEL_BVH4Q ? launch_paths<MODE, ACCEL_BVH4Q>(h, dc, p, film, total)                      \
                               : launch_paths<MODE, ACCEL_BVH2>(h, dc, p, film, total))
     rc = p->mode == RT_MODE_REF_EXACT ? RT_PATHS(RT_MODE_REF_EXACT) : RT_PATHS(RT_MODE_BOOK3);
 #undef RT_PATHS
@@ -594,8 +672,8 @@ extern "C" {
 #ifdef RT_REGROUP_STATS
 // instrumented builds only: turns and lanes per step of k_paths_regroup since the last call
 int rt_debug_regroup_stats(unsigned long long *out) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rg_stats), sizeof(unsigned long long) * 3 * RG_LISTS) != hipSuccess) return -1;
-    unsigned long long zero[3 * RG_LISTS] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rg_stats), sizeof(unsigned long long) * 3 * RG_STATS) != hipSuccess) return -1;
+    unsigned long long zero[3 * RG_STATS] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -655,6 +733,7 @@ void rt_destroy(rt_handle *h) {
     free_queue(h);
     if (h->film && h->film_owned) (void)hipFree(h->film);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->spill) (void)hipFree(h->spill);
     if (h->d_ctrl) (void)hipFree(h->d_ctrl);
     if (h->d_sc) (void)hipFree(h->d_sc);
     if (h->d_cam) (void)hipFree(h->d_cam);
@@ -698,14 +777,30 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     RT_HIP(hipSetDevice(h->device));
     if (validate_scene(h, s)) return -1;
     RT_HIP(hipStreamSynchronize(h->stream));
-    free_scene(h);
+    // The scene in place stays until the new one is complete: a rejected upload leaves the handle
+    // as it was.
+    std::vector<void *> old_allocs;
+    old_allocs.swap(h->scene_allocs);
+    struct {
+        bool flat;
+        int accel;
+        uint32_t stack4, lds_nodes4;
+        accel::Stats stats;
+    } const keep{h->flat, h->accel, h->stack4, h->lds_nodes4, h->accel_stats};
+    auto rollback = [&]() {
+        for (void *p : h->scene_allocs) (void)hipFree(p);
+        h->scene_allocs.swap(old_allocs);
+        h->flat = keep.flat, h->accel = keep.accel, h->stack4 = keep.stack4, h->lds_nodes4 = keep.lds_nodes4, h->accel_stats = keep.stats;
+        return -1;
+    };
     DScene d{};
     static_assert(sizeof(rt_quad) == 96 && sizeof(rt_sphere) == 48 && sizeof(rt_node) == 64, "record sizes");
     static_assert(sizeof(rt_material) == 32 && sizeof(rt_texture) == 32 && sizeof(rt_medium) == 32, "record sizes");
     const rt_quad *dq;
     const rt_sphere *ds;
     const float *dnv;
-    const Node4 *dn4;
+    const Node4 *dn4 = nullptr;
+    const Node4Q *dn4q = nullptr;
     // device copy of the materials: a SolidColor texture is folded into the material record
     // (albedo + pad = 1) so that shading such a surface does not chase the texture record
     std::vector<rt_material> mats(s->materials, s->materials + s->n_materials);
@@ -771,6 +866,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     }
     // structure the kernels will search
     std::vector<Node4> nodes4;
+    std::vector<Node4Q> nodes4q;
     h->stack4 = h->lds_nodes4 = 0;
     h->accel_stats = accel::Stats();
     if (h->flat) {
@@ -778,16 +874,30 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     } else if (h->width == 4) {
         uint32_t root4 = 0;
         std::string err = accel::build_wide_bvh(s, h->build, nodes4, root4, h->accel_stats);
-        if (!err.empty()) return fail(h, "rt_upload_scene: " + err);
+        if (!err.empty()) {
+            fail(h, "rt_upload_scene: " + err);
+            return rollback();
+        }
         // one LDS column per lane, 1 KB per entry per block: up to 40 entries leave 4 blocks per CU
         // (160 KB of LDS), deeper trees run at lower occupancy, 64 entries is the 64 KB block limit
         if (h->accel_stats.stack_need <= 64 && nodes4.size() < (1u << 25)) { // byte offsets of nodes stay 32-bit
-            h->accel = ACCEL_BVH4;
+            // byte boxes pay once the tree no longer lives in LDS and L2 (measured: +5 % from 16 k nodes, +26 %
+            // at 466 k; the decode costs 3-7 % on trees of hundreds of nodes, which are issue-bound)
+            const bool byte_boxes = h->boxes == rt_handle::BOXES_BYTE || (h->boxes == rt_handle::BOXES_AUTO && nodes4.size() >= 8192);
+            h->accel = byte_boxes ? ACCEL_BVH4Q : ACCEL_BVH4;
+            if (h->accel == ACCEL_BVH4Q) {
+                accel::quantise_nodes(nodes4, nodes4q);
+                const std::string bad = accel::verify_quantised(nodes4, nodes4q);
+                if (!bad.empty()) {
+                    fail(h, "rt_upload_scene: " + bad);
+                    return rollback();
+                }
+            }
             h->stack4 = std::max(8u, (h->accel_stats.stack_need + 3u) & ~3u);
             // what is left of a quarter of the CU's 160 KB (four resident blocks) holds the top of the tree
             // (measured: 52 or 64 KB per block stage more nodes but lose a resident block: slower)
             const size_t budget = 40 * 1024, stack_bytes = size_t(h->stack4) * BLOCK * sizeof(uint32_t);
-            h->lds_nodes4 = stack_bytes < budget ? uint32_t(std::min<size_t>(nodes4.size(), (budget - stack_bytes) / sizeof(Node4))) : 0u;
+            h->lds_nodes4 = stack_bytes < budget ? uint32_t(std::min<size_t>(nodes4.size(), (budget - stack_bytes) / h->node4_bytes())) : 0u;
         } else {
             nodes4.clear(); // too deep for the LDS stack of the wide traversal: binary nodes as given
             h->accel = ACCEL_BVH2;
@@ -795,9 +905,16 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     } else {
         h->accel = ACCEL_BVH2;
     }
-    if (h->accel == ACCEL_BVH2 && s->max_stack > uint32_t(STACK_DEPTH))
-        return fail(h, "rt_upload_scene: scene needs a deeper traversal stack than the kernels provide (" +
-                           std::to_string(s->max_stack) + " > " + std::to_string(STACK_DEPTH) + ")");
+    if (h->accel == ACCEL_BVH2) {
+        // the binary traversal drops pushes beyond its fixed LDS stack: refuse instead of missing hits
+        // (recomputed here; the descriptor's max_stack is the caller's word)
+        const uint32_t need = std::max(binary_stack_need(s), s->max_stack);
+        if (need > uint32_t(STACK_DEPTH)) {
+            fail(h, "rt_upload_scene: scene needs a deeper traversal stack than the kernels provide (" + std::to_string(need) + " > " +
+                        std::to_string(STACK_DEPTH) + ")");
+            return rollback();
+        }
+    }
     d.n_nodes4 = uint32_t(nodes4.size());
     d.stack4 = h->stack4;
     d.lds_nodes4 = h->lds_nodes4;
@@ -834,25 +951,32 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.n_flat_boxes = uint32_t(flat_boxes.size() / 32);
     if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, spheres.data(), spheres.size(), &ds) ||
-        upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || upload(h, nodes4.data(), nodes4.size(), &dn4) ||
+        upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || (h->accel == ACCEL_BVH4Q ? upload(h, nodes4q.data(), nodes4q.size(), &dn4q) : upload(h, nodes4.data(), nodes4.size(), &dn4)) ||
         upload(h, flat_other.data(), flat_other.size(), &d.flat_other) ||
         upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
         upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) ||
         upload(h, s->texels, s->n_texel_bytes, &d.texels) || upload(h, s->noise_vec, size_t(s->n_noise) * 1024, &dnv) ||
-        upload(h, s->noise_perm, size_t(s->n_noise) * 768, &d.noise_perm)) {
-        free_scene(h);
-        return -1;
-    }
+        upload(h, s->noise_perm, size_t(s->n_noise) * 768, &d.noise_perm))
+        return rollback();
     d.quads = reinterpret_cast<const float4 *>(dq);
     d.spheres = reinterpret_cast<const float4 *>(ds);
     d.noise_vec = reinterpret_cast<const float4 *>(dnv);
-    d.nodes4 = reinterpret_cast<const float4 *>(dn4);
+    d.nodes4 = h->accel == ACCEL_BVH4Q ? reinterpret_cast<const float4 *>(dn4q) : reinterpret_cast<const float4 *>(dn4);
     d.root = s->root;
     d.n_lights = s->n_lights;
     d.lights_kind = s->lights_kind;
     d.n_nodes = s->n_nodes;
-    RT_HIP(hipMemcpyAsync(h->d_sc, &d, sizeof(DScene), hipMemcpyHostToDevice, h->stream));
-    RT_HIP(hipStreamSynchronize(h->stream));
+    {
+        hipError_t e = hipMemcpyAsync(h->d_sc, &d, sizeof(DScene), hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { // d_sc may hold the new descriptor already: no scene rather than a mixed one
+            fail(h, std::string("rt_upload_scene: ") + hipGetErrorString(e));
+            rollback();
+            free_scene(h);
+            return -1;
+        }
+    }
+    for (void *p : old_allocs) (void)hipFree(p);
     h->sc = d;
     h->have_scene = true;
     h->has_media = s->n_media ? 1u : 0u;
@@ -876,12 +1000,16 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
 
 int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width) {
     if (!h) return -1;
+    if ((builder & RT_BUILD_FP32_BOXES) && (builder & RT_BUILD_BYTE_BOXES)) return fail(h, "rt_set_accel: fp32 boxes or byte boxes, not both");
+    const int boxes = (builder & RT_BUILD_FP32_BOXES) ? rt_handle::BOXES_FP32 : (builder & RT_BUILD_BYTE_BOXES) ? rt_handle::BOXES_BYTE : rt_handle::BOXES_AUTO;
+    builder &= ~(RT_BUILD_FP32_BOXES | RT_BUILD_BYTE_BOXES);
     if (builder > RT_BUILD_AUTO) return fail(h, "rt_set_accel: unknown builder");
     if (width != 2 && width != 4) return fail(h, "rt_set_accel: width must be 2 or 4");
     if (width == 2 && builder != RT_BUILD_REFERENCE)
         return fail(h, "rt_set_accel: the binary traversal walks the descriptor's own nodes; regrouping needs width 4");
     h->build = builder;
     h->width = width;
+    h->boxes = boxes;
     return 0;
 }
 
@@ -902,7 +1030,12 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
     if (out) {
         out->kind = uint32_t(ACCEL_BVH4);
         out->nodes = st.nodes, out->depth = st.depth, out->stack_entries = st.stack_need, out->cost = st.cost;
-        out->flat_quads = out->flat_boxes = out->flat_alone_spheres = out->pad = 0;
+        out->flat_quads = out->flat_boxes = out->flat_alone_spheres = 0;
+        out->node_bytes = uint32_t(sizeof(Node4Q));
+        std::vector<Node4Q> q;
+        accel::quantise_nodes(nodes, q);
+        e = accel::verify_quantised(nodes, q);
+        if (!e.empty()) return say("rt_accel_selftest: " + e);
     }
     return 0;
 }
@@ -910,15 +1043,16 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     if (!h || !out) return -1;
     if (!h->have_scene) return fail(h, "rt_get_accel_info: no scene uploaded");
-    out->kind = uint32_t(h->accel);
-    out->nodes = h->accel == ACCEL_BVH4 ? h->accel_stats.nodes : (h->accel == ACCEL_BVH2 ? h->sc.n_nodes : 0u);
-    out->depth = h->accel == ACCEL_BVH4 ? h->accel_stats.depth : 0u;
-    out->stack_entries = h->accel == ACCEL_BVH4 ? h->stack4 : (h->accel == ACCEL_BVH2 ? uint32_t(STACK_DEPTH) : 0u);
-    out->cost = h->accel == ACCEL_BVH4 ? h->accel_stats.cost : 0.0;
+    const bool wide = accel_is_wide(h->accel);
+    out->kind = wide ? uint32_t(ACCEL_BVH4) : uint32_t(h->accel);
+    out->nodes = wide ? h->accel_stats.nodes : (h->accel == ACCEL_BVH2 ? h->sc.n_nodes : 0u);
+    out->depth = wide ? h->accel_stats.depth : 0u;
+    out->stack_entries = wide ? h->stack4 : (h->accel == ACCEL_BVH2 ? uint32_t(STACK_DEPTH) : 0u);
+    out->cost = wide ? h->accel_stats.cost : 0.0;
+    out->node_bytes = wide ? uint32_t(h->node4_bytes()) : (h->accel == ACCEL_BVH2 ? uint32_t(sizeof(rt_node)) : 0u);
     out->flat_quads = h->accel == ACCEL_FLAT ? h->sc.n_flat_quads : 0u;
     out->flat_boxes = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes : 0u;
     out->flat_alone_spheres = h->alone_spheres;
-    out->pad = 0;
     return 0;
 }
 
@@ -1120,6 +1254,8 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
                 k_extend<ACCEL_FLAT><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
             else if (h->accel == ACCEL_BVH4)
                 k_extend<ACCEL_BVH4><<<grid, block, dyn_lds, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
+            else if (h->accel == ACCEL_BVH4Q)
+                k_extend<ACCEL_BVH4Q><<<grid, block, dyn_lds, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
             else
                 k_extend<ACCEL_BVH2><<<grid, block, 0, h->stream>>>(h->q, h->d_sc, k0, k1, h->has_media);
             tm.end(e);
@@ -1203,6 +1339,9 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
         else if (h->accel == ACCEL_BVH4)
             k_intersect_batch<ACCEL_BVH4><<<grid, block, dyn_lds, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax,
                                                                                d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
+        else if (h->accel == ACCEL_BVH4Q)
+            k_intersect_batch<ACCEL_BVH4Q><<<grid, block, dyn_lds, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax,
+                                                                                d_i, d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));
         else
             k_intersect_batch<ACCEL_BVH2><<<grid, block, 0, h->stream>>>(h->d_sc, n, d_o, d_d, d_time, d_from, tmin, tmax, d_i,
                                                                          d_i + n, d_f, d_f + n, d_f + 2 * size_t(n));

@@ -20,6 +20,7 @@
 //              film accumulation (camera.rs:451-470), compaction of surviving rays.
 #pragma once
 #include "rt_math.h"
+#include "rt_leafword.h"
 #include <type_traits>
 #include "../../include/rt_amd.h"
 
@@ -67,7 +68,8 @@ struct DScene {
     // runs of six quads at the end of the list's quads that are the faces of one rectangular box
     // (box3, hittable.rs:398-455, under any rigid map): 32 floats each, see scan_flat
     const float *flat_boxes;
-    // 4-wide BVH derived at upload (rt_accel.h): 8 float4 per node, root = node 0
+    // 4-wide BVH derived at upload (rt_accel.h), root = node 0: 8 float4 per node (fp32 boxes) or 4
+    // (quantised boxes)
     const float4 *nodes4;
     uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_pairs, n_flat_other, n_nodes4, n_flat_boxes;
     // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
@@ -75,7 +77,10 @@ struct DScene {
 };
 
 // which structure a kernel instance searches
-enum : int { ACCEL_FLAT = 0, ACCEL_BVH2 = 1, ACCEL_BVH4 = 2 };
+// ACCEL_BVH4Q: the 4-wide tree with 64-byte nodes whose child boxes are 8-bit offsets on a grid of
+// the node's own (see trav4_round); ACCEL_BVH4: the same tree with 128-byte fp32 nodes.
+enum : int { ACCEL_FLAT = 0, ACCEL_BVH2 = 1, ACCEL_BVH4 = 2, ACCEL_BVH4Q = 3 };
+constexpr bool accel_is_wide(int accel) { return accel == ACCEL_BVH4 || accel == ACCEL_BVH4Q; }
 
 struct DCamera {
     V3 p00_rel, du, dv, center, disk_u, disk_v, bg;
@@ -116,6 +121,7 @@ struct Best {
     float t;
     uint32_t ref;
     float u, v; // surface coordinates; the flat scan leaves a quad's for quad_uv (below)
+    uint32_t cls; // wide traversal only: RT4_CLASS_* of the hit's material (rt_accel.h)
 };
 
 // A 16-byte record element either per lane (vector load) or wave-uniform (scalar load).
@@ -447,8 +453,8 @@ __device__ __forceinline__ void traverse(SceneRef sc, V3 o, V3 d, float time, fl
 // ray starts there, and a per-lane 16-byte read costs the LDS a fraction of what 64 scattered
 // cache lines cost the vector memory path.  A lane reads a node through a generic pointer that
 // points into LDS or into global memory, so both cases are one instruction stream.
-__device__ __forceinline__ void stage_nodes4(SceneRef sc, uint32_t *s_dyn) {
-    const uint32_t n = sc.lds_nodes4 * 8u;
+template <bool QUANT> __device__ __forceinline__ void stage_nodes4(SceneRef sc, uint32_t *s_dyn) {
+    const uint32_t n = sc.lds_nodes4 * (QUANT ? 4u : 8u);
     float4 *dst = reinterpret_cast<float4 *>(s_dyn + size_t(sc.stack4) * BLOCK);
     for (uint32_t i = threadIdx.x; i < n; i += BLOCK) dst[i] = sc.nodes4[i];
     __syncthreads();
@@ -463,24 +469,141 @@ __device__ __forceinline__ void trav4_begin(float thi, uint32_t &cur, uint32_t &
     best.t = thi;
     best.ref = RT_REF_NONE;
     best.u = best.v = 0.f;
+    best.cls = RT4_CLASS_END; // a miss ends the path like a light
     sp = 0;
     cur = RT_KIND_NODE << RT_REF_KIND_SHIFT; // node 0
 }
-template <bool STAGED>
-__device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
-                                            const RayCtx &rc, uint32_t *s_dyn, uint32_t &cur, uint32_t &sp, Best &best) {
-    uint32_t *stack = s_dyn + threadIdx.x;
-    typedef float v2f __attribute__((ext_vector_type(2))); // two children per packed instruction
-    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-    const v2f ix = {rcp(d.x), rcp(d.x)}, iy = {rcp(d.y), rcp(d.y)}, iz = {rcp(d.z), rcp(d.z)};
+// Where a lane's traversal keeps its stack and finds staged nodes.  The stack is a column of an LDS
+// array (entry i at stack[i * stride]).  SPILL: only the first lds_entries entries live there, deeper
+// ones in global memory (entry i at spill[(i - lds_entries) * spill_stride]) -- for kernels that
+// need the LDS for something else; pushes beyond a handful of pending siblings are rare.
+struct TravMem {
+    uint32_t *stack;
+    uint32_t stride;
+    const char *l_nodes;  // LDS copy of the first nodes
+    uint32_t lds_bytes;   // of l_nodes
+    uint32_t lds_entries; // SPILL only
+    uint32_t *spill;      // SPILL only: this lane's column
+    uint32_t spill_stride;
+};
+__device__ __forceinline__ TravMem block_trav_mem(SceneRef sc, uint32_t *s_dyn, uint32_t node_bytes) {
+    // kernels whose whole dynamic LDS is [stack4][BLOCK] stack words followed by the staged nodes
+    return TravMem{s_dyn + threadIdx.x, uint32_t(BLOCK), reinterpret_cast<const char *>(s_dyn + size_t(sc.stack4) * BLOCK),
+                   sc.lds_nodes4 * node_bytes, 0u, nullptr, 0u};
+}
+template <bool SPILL> __device__ __forceinline__ void trav_push(const TravMem &m, uint32_t &sp, uint32_t v) {
+    if (!SPILL || sp < m.lds_entries) m.stack[sp * m.stride] = v;
+    else m.spill[(sp - m.lds_entries) * m.spill_stride] = v;
+    ++sp;
+}
+template <bool SPILL> __device__ __forceinline__ uint32_t trav_pop(const TravMem &m, uint32_t &sp) {
+    --sp;
+    if (!SPILL || sp < m.lds_entries) return m.stack[sp * m.stride];
+    return m.spill[(sp - m.lds_entries) * m.spill_stride];
+}
+// QUANT: 64-byte nodes.  The child boxes are bytes on a grid of the node's own -- plane = origin +
+// q * 2^e per axis, lower planes rounded down and upper planes up by the builder (rt_accel.h), so a
+// quantised box contains the fp32 one and the closest hit is unchanged; only a few more boxes are
+// entered.  A visit is four 16-byte loads per lane instead of seven and half the bytes: on a large
+// scene the vector memory path, not arithmetic, is what a traversal step costs.
+//   dwords 0-2 origin, 3 = exponents (biased, one byte per axis), 4-6 lower planes x y z (one byte
+//   per child), 7-9 upper planes, 10-11 unused, 12-15 child refs
+// t = (origin + q s - o) / d is evaluated as q * (s / d) + (origin - o) / d: two constants per axis
+// and node, then one conversion and one fma per plane.
+// One visit of a 4-wide node: its four child boxes against the ray, the children that are met
+// sorted nearest first.  key[i] = the entry distance's bits (tn >= tlo > 0: float order = unsigned
+// order), 0xFFFFFFFF for a child that is missed or absent; ref[i] = the child's word.
+struct RayConsts { // per ray, hoisted out of a traversal loop by the caller
+    float ox, oy, oz, ix, iy, iz;
+    uint32_t nx, ny, nz, fx, fy, fz; // fp32 nodes: byte offsets of the near / far planes by the direction's signs
+    bool dnx, dny, dnz;              // byte-box nodes: the ray travels downwards on that axis
+};
+__device__ __forceinline__ RayConsts ray_consts(V3 o, V3 d) {
+    RayConsts c;
+    c.ox = o.x, c.oy = o.y, c.oz = o.z;
+    c.ix = rcp(d.x), c.iy = rcp(d.y), c.iz = rcp(d.z);
     // The plane a ray meets first on each axis follows from the sign of its direction, so the
     // near and far planes are chosen by the load address (lo at float4 0..2, hi at 3..5) and no
     // per-axis min/max is needed.  Sign bit, not `< 0`: -0 has reciprocal -inf.
-    const uint32_t nx = (fbits(d.x) >> 31) * 48u, ny = 16u + (fbits(d.y) >> 31) * 48u, nz = 32u + (fbits(d.z) >> 31) * 48u;
-    const uint32_t fx = 48u - nx, fy = 80u - ny, fz = 112u - nz; // the other plane of each axis
+    c.dnx = (fbits(d.x) >> 31) != 0u, c.dny = (fbits(d.y) >> 31) != 0u, c.dnz = (fbits(d.z) >> 31) != 0u;
+    c.nx = (fbits(d.x) >> 31) * 48u, c.ny = 16u + (fbits(d.y) >> 31) * 48u, c.nz = 32u + (fbits(d.z) >> 31) * 48u;
+    c.fx = 48u - c.nx, c.fy = 80u - c.ny, c.fz = 112u - c.nz;
+    return c;
+}
+template <bool STAGED, bool QUANT>
+__device__ __forceinline__ void wide_node_visit(SceneRef sc, const char *l_nodes, uint32_t lds_bytes, const RayConsts &rcn, float tlo,
+                                                float best_t, uint32_t cur, uint32_t (&key)[4], uint32_t (&ref)[4]) {
+    typedef float v2f __attribute__((ext_vector_type(2))); // two children per packed instruction
+    constexpr uint32_t NODE_BYTES = QUANT ? 64u : 128u;
     const char *g_nodes = reinterpret_cast<const char *>(sc.nodes4);
-    const char *l_nodes = reinterpret_cast<const char *>(s_dyn + size_t(sc.stack4) * BLOCK);
-    const uint32_t lds_bytes = sc.lds_nodes4 * 128u;
+    const v2f ox = {rcn.ox, rcn.ox}, oy = {rcn.oy, rcn.oy}, oz = {rcn.oz, rcn.oz};
+    const v2f ix = {rcn.ix, rcn.ix}, iy = {rcn.iy, rcn.iy}, iz = {rcn.iz, rcn.iz};
+    const uint32_t nx = rcn.nx, ny = rcn.ny, nz = rcn.nz, fx = rcn.fx, fy = rcn.fy, fz = rcn.fz;
+    const uint32_t nb = (cur & RT_REF_INDEX_MASK) * NODE_BYTES; // the wide array stays below 4 GiB (checked at upload)
+    const char *node = (STAGED && nb < lds_bytes ? l_nodes : g_nodes) + nb;
+    auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(node + byte_off); };
+    v2f nx01, nx23, ny01, ny23, nz01, nz23, fx01, fx23, fy01, fy23, fz01, fz23;
+    if constexpr (QUANT) {
+        const float4 h0 = ld(0u), p0 = ld(16u), p1 = ld(32u), cf = ld(48u);
+        ref[0] = fbits(cf.x), ref[1] = fbits(cf.y), ref[2] = fbits(cf.z), ref[3] = fbits(cf.w);
+        const uint32_t ex = fbits(h0.w);
+        const float sx = bitsf((ex & 0xFFu) << 23), sy = bitsf(((ex >> 8) & 0xFFu) << 23), sz = bitsf(((ex >> 16) & 0xFFu) << 23);
+        const v2f ax = {sx * ix.x, sx * ix.x}, ay = {sy * iy.x, sy * iy.x}, az = {sz * iz.x, sz * iz.x};
+        const float bxs = (h0.x - rcn.ox) * ix.x, bys = (h0.y - rcn.oy) * iy.x, bzs = (h0.z - rcn.oz) * iz.x;
+        const v2f bx = {bxs, bxs}, by = {bys, bys}, bz = {bzs, bzs};
+        // the plane a ray meets first on an axis is the lower one unless it travels downwards
+        const uint32_t lox = fbits(p0.x), loy = fbits(p0.y), loz = fbits(p0.z), hix = fbits(p0.w), hiy = fbits(p1.x), hiz = fbits(p1.y);
+        const bool dnx = rcn.dnx, dny = rcn.dny, dnz = rcn.dnz;
+        const uint32_t qnx = dnx ? hix : lox, qfx = dnx ? lox : hix;
+        const uint32_t qny = dny ? hiy : loy, qfy = dny ? loy : hiy;
+        const uint32_t qnz = dnz ? hiz : loz, qfz = dnz ? loz : hiz;
+        auto b01 = [](uint32_t w) { return v2f{float(w & 0xFFu), float((w >> 8) & 0xFFu)}; };
+        auto b23 = [](uint32_t w) { return v2f{float((w >> 16) & 0xFFu), float(w >> 24)}; };
+        // 0 * inf = NaN for a ray parallel to an axis: max3/min3 drop NaN operands, which leaves
+        // that axis unconstrained -- a box entered needlessly, never a box missed
+        nx01 = b01(qnx) * ax + bx, nx23 = b23(qnx) * ax + bx, fx01 = b01(qfx) * ax + bx, fx23 = b23(qfx) * ax + bx;
+        ny01 = b01(qny) * ay + by, ny23 = b23(qny) * ay + by, fy01 = b01(qfy) * ay + by, fy23 = b23(qfy) * ay + by;
+        nz01 = b01(qnz) * az + bz, nz23 = b23(qnz) * az + bz, fz01 = b01(qfz) * az + bz, fz23 = b23(qfz) * az + bz;
+    } else {
+        const float4 ax = ld(nx), ay = ld(ny), az = ld(nz);
+        const float4 bx = ld(fx), by = ld(fy), bz = ld(fz);
+        const float4 cf = ld(96u);
+        ref[0] = fbits(cf.x), ref[1] = fbits(cf.y), ref[2] = fbits(cf.z), ref[3] = fbits(cf.w);
+        // BoundingBox3::hit (boundingbox.rs:96-113) for four boxes; see hit_box for the slack.
+        // 0 * inf = NaN where the origin lies on a plane the ray is parallel to: max3/min3
+        // drop NaN operands, which leaves that axis unconstrained.
+        nx01 = (v2f{ax.x, ax.y} - ox) * ix, nx23 = (v2f{ax.z, ax.w} - ox) * ix;
+        ny01 = (v2f{ay.x, ay.y} - oy) * iy, ny23 = (v2f{ay.z, ay.w} - oy) * iy;
+        nz01 = (v2f{az.x, az.y} - oz) * iz, nz23 = (v2f{az.z, az.w} - oz) * iz;
+        fx01 = (v2f{bx.x, bx.y} - ox) * ix, fx23 = (v2f{bx.z, bx.w} - ox) * ix;
+        fy01 = (v2f{by.x, by.y} - oy) * iy, fy23 = (v2f{by.z, by.w} - oy) * iy;
+        fz01 = (v2f{bz.x, bz.y} - oz) * iz, fz23 = (v2f{bz.z, bz.w} - oz) * iz;
+    }
+    const float tn[4] = {fmaxf(fmaxf(fmaxf(nx01.x, ny01.x), nz01.x), tlo), fmaxf(fmaxf(fmaxf(nx01.y, ny01.y), nz01.y), tlo),
+                         fmaxf(fmaxf(fmaxf(nx23.x, ny23.x), nz23.x), tlo), fmaxf(fmaxf(fmaxf(nx23.y, ny23.y), nz23.y), tlo)};
+    const float tf[4] = {fminf(fminf(fminf(fx01.x, fy01.x), fz01.x), best_t), fminf(fminf(fminf(fx01.y, fy01.y), fz01.y), best_t),
+                         fminf(fminf(fminf(fx23.x, fy23.x), fz23.x), best_t), fminf(fminf(fminf(fx23.y, fy23.y), fz23.y), best_t)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool hit = (tn[i] <= fmaf(fabsf(tf[i]), BOX_SLACK, tf[i])) & (ref[i] != RT_REF_NONE);
+        key[i] = hit ? fbits(tn[i]) : 0xFFFFFFFFu; // tn >= tlo > 0: float order = unsigned order
+    }
+    // sort the four (key, ref) pairs ascending: 5 compare-exchanges
+#define RT_CSWAP(a, b)                                                                       \
+{                                                                                        \
+const bool sw = key[b] < key[a];                                                     \
+const uint32_t ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                 \
+const uint32_t ra_ = sw ? ref[b] : ref[a], rb_ = sw ? ref[a] : ref[b];               \
+key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                                \
+}
+    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+}
+
+template <bool STAGED, bool QUANT = false, bool SPILL = false>
+__device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
+                                            const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best) {
+    const RayConsts rcn = ray_consts(o, d);
     // Node steps run while at least NODE_QUORUM lanes of the wave are at a node (or no lane
     // holds a primitive); then the lanes that hold a primitive test it while the few node
     // lanes wait.  Waiting for the last node lane instead (quorum 1) idles most of the wave.
@@ -490,66 +613,36 @@ __device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time,
         if (n_node == 0) break;
         if (n_node < NODE_QUORUM && __ballot(!at_node && cur != RT_REF_NONE) != 0) break;
         if (!at_node) continue;
-        const uint32_t nb = (cur & RT_REF_INDEX_MASK) * 128u; // the wide array stays below 4 GiB (checked at upload)
-        const char *node = (STAGED && nb < lds_bytes ? l_nodes : g_nodes) + nb;
-        auto ld = [&](uint32_t byte_off) { return *reinterpret_cast<const float4 *>(node + byte_off); };
-        const float4 ax = ld(nx), ay = ld(ny), az = ld(nz);
-        const float4 bx = ld(fx), by = ld(fy), bz = ld(fz);
-        const float4 cf = ld(96u);
-        uint32_t ref[4] = {fbits(cf.x), fbits(cf.y), fbits(cf.z), fbits(cf.w)};
-        // BoundingBox3::hit (boundingbox.rs:96-113) for four boxes; see hit_box for the slack.
-        // 0 * inf = NaN where the origin lies on a plane the ray is parallel to: max3/min3
-        // drop NaN operands, which leaves that axis unconstrained.
-        const v2f nx01 = (v2f{ax.x, ax.y} - ox) * ix, nx23 = (v2f{ax.z, ax.w} - ox) * ix;
-        const v2f ny01 = (v2f{ay.x, ay.y} - oy) * iy, ny23 = (v2f{ay.z, ay.w} - oy) * iy;
-        const v2f nz01 = (v2f{az.x, az.y} - oz) * iz, nz23 = (v2f{az.z, az.w} - oz) * iz;
-        const v2f fx01 = (v2f{bx.x, bx.y} - ox) * ix, fx23 = (v2f{bx.z, bx.w} - ox) * ix;
-        const v2f fy01 = (v2f{by.x, by.y} - oy) * iy, fy23 = (v2f{by.z, by.w} - oy) * iy;
-        const v2f fz01 = (v2f{bz.x, bz.y} - oz) * iz, fz23 = (v2f{bz.z, bz.w} - oz) * iz;
-        const float tn[4] = {fmaxf(fmaxf(fmaxf(nx01.x, ny01.x), nz01.x), tlo), fmaxf(fmaxf(fmaxf(nx01.y, ny01.y), nz01.y), tlo),
-                             fmaxf(fmaxf(fmaxf(nx23.x, ny23.x), nz23.x), tlo), fmaxf(fmaxf(fmaxf(nx23.y, ny23.y), nz23.y), tlo)};
-        const float tf[4] = {fminf(fminf(fminf(fx01.x, fy01.x), fz01.x), best.t), fminf(fminf(fminf(fx01.y, fy01.y), fz01.y), best.t),
-                             fminf(fminf(fminf(fx23.x, fy23.x), fz23.x), best.t), fminf(fminf(fminf(fx23.y, fy23.y), fz23.y), best.t)};
-        uint32_t key[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool hit = (tn[i] <= fmaf(fabsf(tf[i]), BOX_SLACK, tf[i])) & (ref[i] != RT_REF_NONE);
-            key[i] = hit ? fbits(tn[i]) : 0xFFFFFFFFu; // tn >= tlo > 0: float order = unsigned order
-        }
-        // sort the four (key, ref) pairs ascending: 5 compare-exchanges
-#define RT_CSWAP(a, b)                                                                       \
-{                                                                                        \
-    const bool sw = key[b] < key[a];                                                     \
-    const uint32_t ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                 \
-    const uint32_t ra_ = sw ? ref[b] : ref[a], rb_ = sw ? ref[a] : ref[b];               \
-    key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                                \
-}
-        RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
-#undef RT_CSWAP
-        if (key[3] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[3];
-        if (key[2] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[2];
-        if (key[1] != 0xFFFFFFFFu) stack[(sp++) * BLOCK] = ref[1];
+        uint32_t key[4], ref[4];
+        wide_node_visit<STAGED, QUANT>(sc, mem.l_nodes, mem.lds_bytes, rcn, tlo, best.t, cur, key, ref);
+        if (key[3] != 0xFFFFFFFFu) trav_push<SPILL>(mem, sp, ref[3]);
+        if (key[2] != 0xFFFFFFFFu) trav_push<SPILL>(mem, sp, ref[2]);
+        if (key[1] != 0xFFFFFFFFu) trav_push<SPILL>(mem, sp, ref[1]);
         if (key[0] != 0xFFFFFFFFu) {
             cur = ref[0];
         } else if (sp) {
-            cur = stack[(--sp) * BLOCK];
+            cur = trav_pop<SPILL>(mem, sp);
         } else {
             cur = RT_REF_NONE;
         }
     }
     if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
-        test_prim(sc, cur, o, d, time, tlo, origin_ref, rc, best);
-        cur = sp ? stack[(--sp) * BLOCK] : RT_REF_NONE;
+        // a leaf's word carries the class of its material above the index (rt_accel.h)
+        const uint32_t before = best.ref;
+        test_prim(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best);
+        if (best.ref != before) best.cls = (cur & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
+        cur = sp ? trav_pop<SPILL>(mem, sp) : RT_REF_NONE;
     }
 }
 
-template <bool STAGED>
+template <bool STAGED, bool QUANT>
 __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
                                           uint32_t origin_ref, const RayCtx &rc, uint32_t *s_dyn, Best &best) {
     uint32_t cur, sp;
     trav4_begin(thi, cur, sp, best);
+    const TravMem mem = block_trav_mem(sc, s_dyn, QUANT ? 64u : 128u);
     while (__ballot(cur != RT_REF_NONE) != 0) // until every lane of the wave is done
-        trav4_round<STAGED>(sc, o, d, time, tlo, origin_ref, rc, s_dyn, cur, sp, best);
+        trav4_round<STAGED, QUANT>(sc, o, d, time, tlo, origin_ref, rc, mem, cur, sp, best);
 }
 
 // One entry for the three structures.  s_stack / s_nodes: static LDS of the binary traversal;
@@ -710,9 +803,9 @@ __device__ __forceinline__ void closest_hit(SceneRef sc, V3 o, V3 d, float time,
         traverse<USE_LDS_NODES>(sc, o, d, time, tlo, thi, origin_ref, rc, s_stack + threadIdx.x, s_nodes, best);
     else
         if (sc.lds_nodes4) // uniform
-            traverse4<true>(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn, best);
+            traverse4<true, ACCEL == ACCEL_BVH4Q>(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn, best);
         else
-            traverse4<false>(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn, best);
+            traverse4<false, ACCEL == ACCEL_BVH4Q>(sc, o, d, time, tlo, thi, origin_ref, rc, s_dyn, best);
 }
 
 // LDS the three structures need, declared once per kernel
@@ -1009,7 +1102,7 @@ template <int ACCEL>
 __global__ void __launch_bounds__(BLOCK) k_extend(Queue q, const DScene *scp, uint32_t k0, uint32_t k1, uint32_t has_media) {
     SceneRef sc = *as_uniform(scp);
     RT_ACCEL_LDS(ACCEL)
-    if (ACCEL == ACCEL_BVH4) stage_nodes4(sc, s_dyn);
+    if (accel_is_wide(ACCEL)) stage_nodes4<ACCEL == ACCEL_BVH4Q>(sc, s_dyn);
     if (ACCEL == ACCEL_BVH2) { // stage the top of the BVH
         const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
         const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
@@ -1320,7 +1413,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     SceneRef sc = *as_uniform(scp);
     CamRef cam = *as_uniform(camp);
     RT_ACCEL_LDS(ACCEL)
-    if (ACCEL == ACCEL_BVH4) stage_nodes4(sc, s_dyn);
+    if (accel_is_wide(ACCEL)) stage_nodes4<ACCEL == ACCEL_BVH4Q>(sc, s_dyn);
     if (ACCEL == ACCEL_BVH2) {
         const uint32_t nn = min(sc.n_nodes, uint32_t(LDS_NODES));
         const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
@@ -1350,7 +1443,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         bool scatter = false; // the path goes on from a surface
         bool busy = false;    // (wide BVH) this lane is inside a traversal and skips the shading steps
         Surface sf;
-        if constexpr (ACCEL == ACCEL_BVH4) {
+        if constexpr (accel_is_wide(ACCEL)) {
             busy = alive && cur != RT_REF_NONE;
             const uint32_t n_busy = uint32_t(__popcll(__ballot(busy)));
             // lanes with something to do in the shading steps: a finished traversal, or an empty
@@ -1359,10 +1452,11 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
             if (n_busy != 0 && n_work < SHADE_QUORUM) {
                 if (busy) {
                     RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
+                    const TravMem mem = block_trav_mem(sc, s_dyn, ACCEL == ACCEL_BVH4Q ? 64u : 128u);
                     if (sc.lds_nodes4) // uniform
-                        trav4_round<true>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, s_dyn, cur, sp, best);
+                        trav4_round<true, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
                     else
-                        trav4_round<false>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, s_dyn, cur, sp, best);
+                        trav4_round<false, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
                 }
                 continue;
             }
@@ -1386,7 +1480,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         bool fresh = false;
         const unsigned long long idle = __ballot(!scatter && !busy);
         const uint32_t n_idle = uint32_t(__popcll(idle));
-        if (!exhausted && (n_idle >= refill_min || n_idle == WAVE || (ACCEL == ACCEL_BVH4 && n_idle != 0))) {
+        if (!exhausted && (n_idle >= refill_min || n_idle == WAVE || (accel_is_wide(ACCEL) && n_idle != 0))) {
             if (next == end) {
                 // guided self-scheduling: ranges shrink with the work that is left (estimated
                 // from the counter value this wave saw last), so the last waves finish together
@@ -1437,7 +1531,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         } else if (!busy) {
             alive = false;
         }
-        if constexpr (ACCEL == ACCEL_BVH4) { // lanes with a new ray start its traversal
+        if constexpr (accel_is_wide(ACCEL)) { // lanes with a new ray start its traversal
             const bool start = alive && !busy;
             n_seg += uint32_t(__popcll(__ballot(start)));
             if (start) trav4_begin(RT_INF, cur, sp, best);
@@ -1484,8 +1578,9 @@ static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE, "slot numbers are b
 #ifndef RT_REGROUP_WAVES
 #define RT_REGROUP_WAVES 4
 #endif
+constexpr uint32_t RG_STATS = RG_LISTS + 2; // instrumented builds: the lists' steps, then harvest and refill of k_paths_pool
 #ifdef RT_REGROUP_STATS
-__device__ unsigned long long g_rg_stats[3 * RG_LISTS]; // turns, lanes and clock ticks per step (instrumented builds)
+__device__ unsigned long long g_rg_stats[3 * RG_STATS]; // turns, lanes and clock ticks per step (instrumented builds)
 #define RT_RG_COUNT(stage, m) (rg_turns[stage] += 1, rg_lanes[stage] += (m))
 #else
 #define RT_RG_COUNT(stage, m) ((void)0)
@@ -1523,7 +1618,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     unsigned long long n_seg = 0, n_cam = 0;
     bool exhausted = false;
 #ifdef RT_REGROUP_STATS
-    unsigned long long rg_turns[RG_LISTS] = {}, rg_lanes[RG_LISTS] = {}, rg_ticks[RG_LISTS] = {};
+    unsigned long long rg_turns[RG_STATS] = {}, rg_lanes[RG_STATS] = {}, rg_ticks[RG_STATS] = {};
 #endif
     // appends the slots of the lanes where `yes` holds to list `which`
     auto push = [&](uint32_t which, uint32_t &n, bool yes, uint32_t slot) {
@@ -1725,8 +1820,297 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         atomicAdd(&ctrl->segments, n_seg);
         atomicAdd(&ctrl->camera_rays, n_cam);
 #ifdef RT_REGROUP_STATS
-        for (uint32_t i = 0; i < RG_LISTS; ++i)
-            atomicAdd(&g_rg_stats[i], rg_turns[i]), atomicAdd(&g_rg_stats[RG_LISTS + i], rg_lanes[i]), atomicAdd(&g_rg_stats[2 * RG_LISTS + i], rg_ticks[i]);
+        for (uint32_t i = 0; i < RG_STATS; ++i)
+            atomicAdd(&g_rg_stats[i], rg_turns[i]), atomicAdd(&g_rg_stats[RG_STATS + i], rg_lanes[i]), atomicAdd(&g_rg_stats[2 * RG_STATS + i], rg_ticks[i]);
+#endif
+    }
+}
+
+// ------------------------------------------------------------------ persistent path kernel, regrouping behind the wide BVH
+// k_paths behind a tree ties a path to a lane: a lane whose traversal has ended waits for enough
+// others before it is shaded (traversal lengths are heavy-tailed), and the shading code runs for
+// the lanes that happen to need each branch.  On the 1 M-primitive scene that left 38 % of the lanes
+// active, in the vector units and in the memory pipeline alike.  Here, as in k_paths_regroup, every
+// WAVE owns a pool of POOL_SLOTS paths in LDS and one list of slot numbers per kind of pending work;
+// the difference is the closest hit, which takes a different number of steps for every ray: a lane
+// takes a ray from the ray list, keeps its traversal (cur, stack height, closest hit so far) in
+// registers across turns, and hands the hit back to the pool when it is done -- then takes the
+// next ray.  A turn of the wave is one of
+//   * a traversal round for the lanes that hold a ray (trav4_round), while enough of them do;
+//   * harvest and refill: lanes whose traversal has ended write the hit into their slot, which joins
+//     the list of its material's kind; idle lanes take new rays from the ray list;
+//   * a shading turn for up to 64 slots of one list, exactly k_paths_regroup's.
+// LDS: the pool and POOL_STACK stack entries per lane; what a traversal pushes beyond that goes to a
+// per-lane column in global memory (TravMem, SPILL) -- near-first order keeps few siblings pending.
+// Every random number is keyed by (pixel, stratum, bounce), so the image equals k_paths'.
+// Exit: a wave leaves when the sample counter has run out, no lane holds a ray and every list but
+// the free one is empty; every traversal ends (the tree is finite) and every path within max_depth.
+#ifndef RT_POOL_SLOTS
+#define RT_POOL_SLOTS 112
+#endif
+#ifndef RT_POOL_STACK
+#define RT_POOL_STACK 12
+#endif
+#ifndef RT_POOL_HARVEST
+#define RT_POOL_HARVEST 16
+#endif
+#ifndef RT_POOL_STARVE
+#define RT_POOL_STARVE 40
+#endif
+constexpr int POOL_SLOTS = RT_POOL_SLOTS;       // paths per wave
+constexpr uint32_t POOL_STACK = RT_POOL_STACK;  // LDS stack entries per lane
+constexpr uint32_t POOL_HARVEST = RT_POOL_HARVEST; // ended traversals that make the wave stop for a harvest
+constexpr uint32_t POOL_STARVE = RT_POOL_STARVE;   // fewer traversing lanes than this: shade a list even if it is not full
+struct TravPool {
+    float4 ra[POOL_SLOTS], rb[POOL_SLOTS], sa[POOL_SLOTS];
+    uint32_t sb[POOL_SLOTS];
+    uint8_t list[RG_LISTS][POOL_SLOTS];
+};
+static_assert(POOL_SLOTS <= 256 && POOL_SLOTS >= WAVE && POOL_SLOTS % 8 == 0, "slot numbers are bytes; the struct stays 16-byte aligned");
+// dynamic LDS of a block: the pools, then [POOL_STACK][WAVE] stack words per wave, then the staged nodes
+constexpr size_t POOL_LDS_FIXED = (BLOCK / WAVE) * (sizeof(TravPool) + size_t(POOL_STACK) * WAVE * sizeof(uint32_t));
+
+template <int MODE, bool QUANT>
+__global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1,
+                                                        Ctrl *ctrl, uint32_t has_media, uint32_t grab, uint32_t *spill,
+                                                        uint32_t lds_nodes) {
+    SceneRef sc = *as_uniform(scp);
+    CamRef cam = *as_uniform(camp);
+    extern __shared__ uint32_t s_dyn[];
+    TravPool *pools = reinterpret_cast<TravPool *>(s_dyn);
+    uint32_t *stacks = s_dyn + (BLOCK / WAVE) * sizeof(TravPool) / sizeof(uint32_t);
+    float4 *l_nodes = reinterpret_cast<float4 *>(stacks + (BLOCK / WAVE) * POOL_STACK * WAVE);
+    constexpr uint32_t NODE_BYTES = QUANT ? 64u : 128u;
+    { // the only barrier of the kernel: the top of the tree, before any wave takes its first turn
+        const uint32_t n = lds_nodes * (NODE_BYTES / 16u);
+        for (uint32_t i = threadIdx.x; i < n; i += BLOCK) l_nodes[i] = sc.nodes4[i];
+        __syncthreads();
+    }
+    const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    TravPool &pool = pools[wave];
+    const TravMem mem{stacks + wave * POOL_STACK * WAVE + lane, uint32_t(WAVE), reinterpret_cast<const char *>(l_nodes),
+                      lds_nodes * NODE_BYTES, POOL_STACK, spill + (size_t(blockIdx.x) * BLOCK + threadIdx.x), gridDim.x * uint32_t(BLOCK)};
+    for (uint32_t i = lane; i < uint32_t(POOL_SLOTS); i += WAVE) pool.list[RG_FREE][i] = uint8_t(i);
+    uint32_t n_free = POOL_SLOTS, n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0, n_end = 0; // list lengths, wave-uniform
+    const unsigned long long total = ctrl->total_samples;
+    unsigned long long next = 0, end = 0, seen = 0;
+    const float inv_share = 1.0f / (4.0f * float(gridDim.x * (BLOCK / WAVE)));
+    uint32_t next_pixel = 0, next_stratum = 0;
+    unsigned long long n_seg = 0, n_cam = 0;
+    bool exhausted = false;
+    // this lane's traversal
+    bool busy = false; // holds a ray (its slot is in no list)
+    uint32_t slot = 0, cur = RT_REF_NONE, sp = 0;
+    float4 ra = {}, rb = {};
+    RayCtx rc{k0, k1, 0u, 0u, 0u};
+    Best best;
+    best.t = RT_INF, best.ref = RT_REF_NONE, best.u = best.v = 0.f;
+#ifdef RT_REGROUP_STATS
+    unsigned long long rg_turns[RG_STATS] = {}, rg_lanes[RG_STATS] = {}, rg_ticks[RG_STATS] = {};
+    unsigned long long rg_t0 = wall_clock64();
+#define RT_POOL_TICK(stage) { const unsigned long long now_ = wall_clock64(); rg_ticks[stage] += now_ - rg_t0; rg_t0 = now_; }
+#else
+#define RT_POOL_TICK(stage) ((void)0)
+#endif
+
+    auto push = [&](uint32_t which, uint32_t &n, bool yes, uint32_t sl) {
+        const unsigned long long mask = __ballot(yes);
+        if (mask == 0) return; // uniform
+        const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+        if (yes) pool.list[which][n + prefix] = uint8_t(sl);
+        n += uint32_t(__popcll(mask));
+    };
+    // up to `want` new samples (see k_paths_regroup): lanes below the returned count make their
+    // camera ray in `sl`, which joins the rays to trace
+    auto new_paths = [&](uint32_t want, uint32_t sl) -> uint32_t {
+        if (next == end && !exhausted) {
+            const float left = float(total > seen ? total - seen : 0ull);
+            uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
+            take = take < uint32_t(WAVE) ? uint32_t(WAVE) : (take & ~uint32_t(WAVE - 1));
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(take));
+            b = wave_first(b);
+            seen = b;
+            next = b < total ? b : total;
+            end = b + take < total ? b + take : total;
+            exhausted = next == end;
+            next_pixel = uint32_t(next % cam.npix);
+            next_stratum = cam.stratum_begin + uint32_t(next / cam.npix);
+        }
+        const uint32_t m = uint32_t(end - next < want ? end - next : want);
+        if (m == 0) return 0;
+        if (lane < m) {
+            uint32_t px = next_pixel + lane, st = next_stratum;
+            while (px >= cam.npix) px -= cam.npix, ++st;
+            Rng rng;
+            rng.begin(k0, k1, px, st, STREAM_CAMERA, 0);
+            V3 o, d;
+            float time;
+            camera_ray(cam, px, st, rng, o, d, time);
+            pool.ra[sl] = make_float4(o.x, o.y, o.z, time);
+            pool.rb[sl] = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
+            pool.sa[sl] = make_float4(1.f, 1.f, 1.f, bitsf(px));
+            pool.sb[sl] = st;
+            pool.list[RG_RAY][n_ray + lane] = uint8_t(sl);
+        }
+        n_ray += m;
+        next += m;
+        n_cam += m;
+        next_pixel += m;
+        while (next_pixel >= cam.npix) next_pixel -= cam.npix, ++next_stratum;
+        return m;
+    };
+
+    for (;;) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool traversing = busy && cur != RT_REF_NONE;
+        const uint32_t n_trav = uint32_t(__popcll(__ballot(traversing)));
+        const uint32_t n_done = uint32_t(__popcll(__ballot(busy && cur == RT_REF_NONE)));
+        // rays waiting and lanes free to take them, or work that would make rays
+        const uint32_t n_lanes_free = uint32_t(WAVE) - n_trav;
+        const bool can_refill = n_ray != 0 && n_lanes_free >= POOL_HARVEST;
+        const uint32_t fullest = max(max(n_diffuse, n_glass), max(n_metal, n_end));
+        const bool can_shade = fullest >= uint32_t(WAVE) || (fullest != 0 && n_trav < POOL_STARVE && n_ray == 0) ||
+                               (!exhausted && n_free != 0 && n_trav < POOL_STARVE && n_ray == 0);
+        if (n_trav != 0 && n_done < POOL_HARVEST && !can_refill && !can_shade) {
+            // 1. a traversal round for the lanes that hold a ray
+            if (traversing) {
+                if (lds_nodes) // uniform
+                    trav4_round<true, QUANT, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+                else
+                    trav4_round<false, QUANT, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+            }
+            RT_RG_COUNT(RG_RAY, n_trav);
+            RT_POOL_TICK(RG_RAY);
+            continue;
+        }
+        // 2. harvest: ended traversals hand their hit to the pool (camera.rs:444 answered)
+        if (n_done != 0) {
+            const bool done = busy && cur == RT_REF_NONE;
+            uint32_t kind = RG_LISTS;
+            if (done) {
+                const V3 p = fma3(mk(rb), best.t, mk(ra)); // as shade_emit forms it
+                pool.ra[slot] = make_float4(p.x, p.y, p.z, ra.w);
+                pool.rb[slot].w = bitsf(best.ref); // the direction is still there
+                // (a quad's (alpha, beta) are not kept: shade_emit recomputes them from the hit point
+                // for the materials that look at them)
+                // the hit's leaf said what its material asks for (a miss ends the path like a light)
+                kind = best.cls == RT4_CLASS_END ? RG_END : (best.cls == RT4_CLASS_METAL ? RG_METAL : (best.cls == RT4_CLASS_GLASS ? RG_GLASS : RG_DIFFUSE));
+                busy = false;
+            }
+            push(RG_DIFFUSE, n_diffuse, kind == RG_DIFFUSE, slot);
+            push(RG_END, n_end, kind == RG_END, slot);
+            push(RG_GLASS, n_glass, kind == RG_GLASS, slot);
+            push(RG_METAL, n_metal, kind == RG_METAL, slot);
+            RT_RG_COUNT(RG_LISTS, n_done);
+            RT_POOL_TICK(RG_LISTS);
+        }
+        // 3. shading turns: a full list, or whatever there is when the traversal is short of rays
+        {
+            uint32_t stage = RG_LISTS, most = 0;
+            auto offer = [&](uint32_t which, uint32_t n) {
+                const uint32_t c = min(n, uint32_t(WAVE));
+                if (c > most) most = c, stage = which;
+            };
+            offer(RG_DIFFUSE, n_diffuse);
+            offer(RG_GLASS, n_glass);
+            offer(RG_METAL, n_metal);
+            offer(RG_END, n_end);
+            if (!exhausted) offer(RG_FREE, n_free);
+            const uint32_t n_hold = uint32_t(__popcll(__ballot(busy)));
+            const bool starving = n_ray == 0 && n_hold < POOL_STARVE;
+            if (most != 0 && (most >= uint32_t(WAVE) || starving)) {
+                if (stage == RG_FREE) {
+                    const uint32_t sl = lane < most ? pool.list[RG_FREE][n_free - 1 - lane] : 0u;
+                    const uint32_t m = new_paths(most, sl);
+                    n_free -= m;
+                } else if (stage == RG_END) {
+                    const uint32_t m = most;
+                    n_end -= m;
+                    const bool active = lane < m;
+                    uint32_t sl = 0;
+                    if (active) {
+                        sl = pool.list[RG_END][n_end + lane];
+                        const float4 srb = pool.rb[sl];
+                        if (fbits(srb.w) != RG_REF_NOTHING) {
+                            Surface sf; // ra holds the hit point: t = 0 from there
+                            (void)shade_emit<true, false>(sc, cam, film, pool.ra[sl], srb, pool.sa[sl], make_float4(0.f, srb.w, 0.f, 0.f), true, sf);
+                        }
+                    }
+                    const uint32_t taken = new_paths(m, sl);
+                    push(RG_FREE, n_free, active && lane >= taken, sl);
+                } else {
+                    const uint32_t m = most;
+                    auto scatter_turn = [&](auto only, uint32_t &n_list) {
+                        constexpr uint32_t ONLY = decltype(only)::value;
+                        n_list -= m;
+                        const bool active = lane < m;
+                        uint32_t sl = 0;
+                        bool alive = false;
+                        if (active) {
+                            sl = pool.list[stage][n_list + lane];
+                            float4 sra = pool.ra[sl], srb = pool.rb[sl], ssa = pool.sa[sl];
+                            const uint32_t packed = pool.sb[sl];
+                            uint2 ssb = make_uint2(packed & 0xFFFFFFu, packed >> 24);
+                            Surface sf;
+                            (void)shade_emit<false, false>(sc, cam, film, sra, srb, ssa, make_float4(0.f, srb.w, 0.f, 0.f), true, sf);
+                            Rng rng;
+                            rng.begin(k0, k1, fbits(ssa.w), ssb.x, STREAM_SHADE, ssb.y);
+                            alive = shade_scatter<MODE, ONLY>(sc, cam, sra, srb, ssa, ssb, sf, rng, ctrl);
+                            if (alive) {
+                                pool.ra[sl] = sra;
+                                pool.rb[sl] = srb;
+                                pool.sa[sl] = ssa;
+                                pool.sb[sl] = ssb.x | (ssb.y << 24);
+                            } else {
+                                pool.rb[sl].w = bitsf(RG_REF_NOTHING);
+                            }
+                        }
+                        push(RG_RAY, n_ray, alive, sl);
+                        push(RG_END, n_end, active && !alive, sl);
+                    };
+                    if (stage == RG_DIFFUSE) scatter_turn(std::integral_constant<uint32_t, RT_MAT_LAMBERTIAN>{}, n_diffuse);
+                    else if (stage == RG_GLASS) scatter_turn(std::integral_constant<uint32_t, RT_MAT_DIELECTRIC>{}, n_glass);
+                    else scatter_turn(std::integral_constant<uint32_t, RT_MAT_METAL>{}, n_metal);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                RT_RG_COUNT(stage, most);
+                RT_POOL_TICK(stage);
+            } else if (most == 0 && n_hold == 0 && n_ray == 0) {
+                break; // nothing left anywhere (the free list does not count once the samples have run out)
+            }
+        }
+        // 4. refill: lanes without a ray take the rays waiting
+        if (n_ray != 0) {
+            const unsigned long long idle = __ballot(!busy);
+            const uint32_t n_idle = uint32_t(__popcll(idle));
+            const uint32_t m = min(n_idle, n_ray);
+            if (m != 0) {
+                const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(idle >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(idle), 0u));
+                if (!busy && prefix < m) {
+                    slot = pool.list[RG_RAY][n_ray - 1 - prefix];
+                    ra = pool.ra[slot];
+                    rb = pool.rb[slot];
+                    if (has_media) { // a medium keys its free-flight draw by the sample and the bounce
+                        const uint32_t sb = pool.sb[slot];
+                        rc.pixel = fbits(pool.sa[slot].w), rc.sample = sb & 0xFFFFFFu, rc.bounce = sb >> 24;
+                    }
+                    trav4_begin(RT_INF, cur, sp, best);
+                    busy = true;
+                }
+                n_ray -= m;
+                n_seg += m;
+                RT_RG_COUNT(RG_LISTS + 1, m);
+                RT_POOL_TICK(RG_LISTS + 1);
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&ctrl->segments, n_seg);
+        atomicAdd(&ctrl->camera_rays, n_cam);
+#ifdef RT_REGROUP_STATS
+        for (uint32_t i = 0; i < RG_STATS; ++i)
+            atomicAdd(&g_rg_stats[i], rg_turns[i]), atomicAdd(&g_rg_stats[RG_STATS + i], rg_lanes[i]), atomicAdd(&g_rg_stats[2 * RG_STATS + i], rg_ticks[i]);
 #endif
     }
 }
@@ -1739,7 +2123,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(const DScene *scp, ui
                                                             int *prim, float *t, float *u, float *v) {
     SceneRef sc = *as_uniform(scp);
     RT_ACCEL_LDS(ACCEL)
-    if (ACCEL == ACCEL_BVH4) stage_nodes4(sc, s_dyn);
+    if (accel_is_wide(ACCEL)) stage_nodes4<ACCEL == ACCEL_BVH4Q>(sc, s_dyn);
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     V3 o = {o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]}, d = {d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]};

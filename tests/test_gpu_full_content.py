@@ -67,6 +67,12 @@ def test_full_resolution_render_properties(device, name):
     rc = cam.build()
     st = device.render(rc, mode=ra.RT_MODE_BOOK3, seed=1, stratum_begin=0, stratum_end=n_strata)
     whole = device.film().astype(np.float64)
+    assert st.regrouped == (name == "c5")  # a pool of paths per wave behind the large tree, lane-bound paths behind the small ones
+    if name == "c5":  # both variants of the persistent kernel trace the same samples at this size too
+        device.film_clear()
+        other = device.render(rc, mode=ra.RT_MODE_BOOK3, seed=1, stratum_begin=0, stratum_end=n_strata, regroup=False)
+        assert not other.regrouped and other.camera_rays == st.camera_rays and abs(other.segments - st.segments) <= 1e-4 * st.segments
+        assert (~np.isclose(device.film().astype(np.float64), whole, rtol=1e-4, atol=1e-5)).mean() < 1e-3
     assert st.camera_rays == W * H * n_strata
     assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.max() > 0.0
     assert st.dropped <= 1e-6 * st.segments + 2, (st.dropped, st.segments)

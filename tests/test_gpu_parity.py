@@ -82,25 +82,30 @@ def test_intersection_parity_fixed_batch(device, name):
 
 
 ACCELS = [("reference", 4), ("sah", 4), ("reference", 2)]
+BOX_FORMATS = {"fp32-boxes": True, "byte-boxes": False}  # 128-byte and 64-byte wide nodes
 
 
+@pytest.mark.parametrize("boxes", list(BOX_FORMATS))
 @pytest.mark.parametrize("name", ["c2", "c4", "c5"])
-def test_acceleration_structures_agree(device, name):
+def test_acceleration_structures_agree(device, name, boxes):
     """The closest hit does not depend on the grouping: the 4-wide BVH with the descriptor's
     grouping, with a surface-area regrouping, and the binary nodes as given must return the
-    same primitive at the same t for every ray (both pipelines share these searches)."""
+    same primitive at the same t for every ray (both pipelines share these searches) -- with the
+    wide nodes' child boxes as fp32 or as bytes on the node's own grid (rounded outward: a few
+    more boxes entered, the same hits)."""
     host, osb, cam, mode, bbox = scene(name, device)
     o, d, tm, frm = helpers.ray_batch(osb, cam, 65536, seed=5, bbox=bbox)
     results, infos = [], []
     try:
         for builder, width in ACCELS:
-            device.set_accel(builder, width)
+            device.set_accel(builder, width, fp32_boxes=BOX_FORMATS[boxes] if width == 4 else None)
             device.upload(host)
             infos.append(device.accel_info())
             results.append(device.intersect_batch(o, d, tm, origin_prim=frm))
     finally:
         device.set_accel("auto", 4)
     assert [i["kind"] for i in infos] == ["bvh4", "bvh4", "bvh2"], infos
+    assert [i["node_bytes"] for i in infos] == [128 if BOX_FORMATS[boxes] else 64] * 2 + [64], infos
     assert infos[0]["stack_entries"] <= 40 and infos[0]["nodes"] < infos[2]["nodes"]
     hit0, prim0, t0, u0, v0 = results[2]
     assert 0.2 < hit0.mean() <= 1.0
@@ -115,16 +120,16 @@ def test_acceleration_structures_agree(device, name):
         assert np.array_equal(t[agree], t0[agree]) and np.array_equal(u[agree], u0[agree], equal_nan=True)
 
 
-@pytest.mark.parametrize("builder,width", ACCELS[1:])
+@pytest.mark.parametrize("builder,width,fp32_boxes", [("sah", 4, True), ("sah", 4, False), ("reference", 4, False), ("reference", 2, None)])
 @pytest.mark.parametrize("name", ["c2", "c4"])
-def test_render_with_other_acceleration_structures(device, name, builder, width):
+def test_render_with_other_acceleration_structures(device, name, builder, width, fp32_boxes):
     host, osb, cam, mode, _ = scene(name, device)
     rc = cam.build()
     device.film_resize(cam.image_width, cam.image_height)
     device.render(rc, mode=mode, seed=3)
     base = device.film().astype(np.float64)
     try:
-        device.set_accel(builder, width)
+        device.set_accel(builder, width, fp32_boxes=fp32_boxes)
         device.upload(host)
         device.film_clear()
         device.render(rc, mode=mode, seed=3)
@@ -202,15 +207,13 @@ FORKED = 5e-4
 def test_render_same_stream_pixelwise(device, name, med, frac, pipeline):
     """Same uniforms on both sides: almost every pixel agrees to fp32 accuracy; the few that do
     not are paths that forked at an fp32-vs-f64 decision (edge, rejection loop, Schlick draw)."""
-    if pipeline in ("lane-bound", "regrouped") and name not in FLAT_WORLDS:
-        pytest.skip("the persistent kernel has one variant behind a BVH")
     host, osb, cam, mode, _ = scene(name, device)
     rc = cam.build()
     device.film_resize(cam.image_width, cam.image_height)
     st = device.render(rc, mode=mode, seed=1, **PIPELINES[pipeline])
     if pipeline in ("lane-bound", "regrouped"):
         assert st.regrouped == (pipeline == "regrouped")
-    if pipeline == "persistent":  # the library's choice: regrouping on a flat world
+    if pipeline == "persistent":  # the library's choice: regrouping on a flat world, behind a tree only when it is large
         assert st.regrouped == (name in FLAT_WORLDS)
     gpu = device.film(1.0 / cam.effective_spp)
     film, _, cnt = orc.render(osb, cam, mode=mode, seed=1)
@@ -704,6 +707,31 @@ def test_upload_validation_rejects_bad_descriptors(device):
     finally:
         device.set_accel("auto", 4)
     device.upload_desc(bdesc)
+    # ... and it is recomputed from the nodes, whatever the descriptor claims: a chain of 40 two-object
+    # BVHNodes needs 40 entries; with max_stack understated the upload is still refused, and the
+    # scene uploaded before stays in place (a rejected upload changes nothing)
+    chain = ra.SceneBuilder()
+    grey = chain.lambertian((0.5, 0.5, 0.5))
+    node = chain.sphere((0.0, 0.0, -40.0), 0.4, grey)
+    for k in range(40):
+        node = chain.bvh([chain.sphere((0.0, 0.0, -39.0 + k), 0.4, grey), node])
+    chain.set_world(chain.list([node]))
+    chain.set_lights(None)
+    cdesc = chain.flatten()
+    assert cdesc.contents.max_stack >= 40
+    cdesc.contents.max_stack = 0
+    before = device.accel_info()
+    try:
+        device.set_accel("reference", 2)
+        with pytest.raises(ra.RtError, match="deeper traversal stack"):
+            device.upload_desc(cdesc)
+    finally:
+        device.set_accel("auto", 4)
+    assert device.accel_info() == before
+    o = np.array([[13.0, 2.0, 3.0]], np.float32)
+    assert device.intersect_batch(o, -o)[0][0] == 1  # the Book-1 miniature still answers
+    device.upload_desc(cdesc)  # the wide structure sizes its own stack
+    assert device.accel_info()["kind"] == "bvh4" and device.intersect_batch(np.zeros((1, 3), np.float32), np.float32([[0, 0, -1]]))[0][0] == 1
     with pytest.raises(ra.RtError, match="width"):
         device.set_accel("reference", 3)
     with pytest.raises(ra.RtError, match="regrouping"):

@@ -18,3 +18,8 @@ run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum &&
 run tcc2 FETCH_SIZE TCC_EA0_RDREQ_sum &&
 run tcc3 WRITE_SIZE TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum &&
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+# vector memory path (the BVH workloads live here): L1 accesses, stalls, latency, address translation
+run tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum &&
+run tcp2 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_GATE_EN2_sum &&
+run tcp3 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TA_TCP_STATE_READ_sum &&
+run ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE
