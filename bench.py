@@ -67,10 +67,11 @@ PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 510 + 4073925) * 1024 / 861.4e6,
                          ("c3", False): (2 * 12796 + 4905618) * 1024 / 861.4e6}
 
 
-def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads):
+def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads, shrink=1):
     """The oracle (C++ f64 restatement of the reference) on a bounded sample of the workload:
-    the full frame for `n_strata_sample` of the strata.  Test infrastructure used as a checker
-    and as the reported baseline only."""
+    the full frame for `n_strata_sample` of the strata -- at 1/shrink of the resolution per axis
+    where the full frame would take minutes (same scene, same camera, same path statistics).  Test
+    infrastructure used as a checker and as the reported baseline only."""
     from oracle import config_oracle
     from oracle import oracle_py as orc
     osb = orc.scene()
@@ -78,6 +79,8 @@ def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads):
     if scene_fn in (ra.scenes.cornell_main, ra.scenes.cornell_book3):
         kw["toml_objects"] = config_oracle.toml_objects
     cam = scene_fn(osb, **kw)
+    if shrink > 1:
+        cam.image_width, cam.image_height = max(2, cam.image_width // shrink), max(2, cam.image_height // shrink)
     t0 = time.perf_counter()
     _, _, cnt = orc.render(osb, cam, mode=mode, seed=1, stratum_begin=0, stratum_end=n_strata_sample, threads=threads)
     dt = time.perf_counter() - t0
@@ -226,16 +229,20 @@ def main():
            "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": int(seg_per_launch),
            "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]), "timed_launches": int(timed[k])}
     if world == 1 and not args.no_cpu_baseline:
-        cnt, dt, _ = cpu_baseline(scene_fn, kw, mode, args.cpu_strata, threads=1)
+        # a bounded sample: strata of the full frame, the frame shrunk where a stratum alone takes minutes
+        cpu_strata, shrink = {"c3": (args.cpu_strata, 1), "c1": (16, 1), "c2": (4, 1), "c4": (2, 1), "c5": (1, 8)}[args.workload]
+        frame = "full frame" if shrink == 1 else f"frame at 1/{shrink} of the resolution per axis"
+        cnt, dt, _ = cpu_baseline(scene_fn, kw, mode, cpu_strata, threads=1, shrink=shrink)
         fps = flops_per_segment(cnt)
         out["cpu_baseline"] = {"value": round(cnt["segments"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                               "sample": f"full frame, {args.cpu_strata} of {n_strata} strata ({cnt['camera_rays']} camera rays, "
+                               "sample": f"{frame}, {cpu_strata} of {n_strata} strata ({cnt['camera_rays']} camera rays, "
                                          f"{cnt['segments']} segments, {dt:.1f} s); C++ f64 restatement of the reference, not the Rust binary"}
         nthreads = min(16, os.cpu_count() or 1)
-        cnt2, dt2, _ = cpu_baseline(scene_fn, kw, mode, max(args.cpu_strata, 8), threads=nthreads)
+        many = max(cpu_strata, 8) if args.workload in ("c3", "c1") else cpu_strata * 4
+        cnt2, dt2, _ = cpu_baseline(scene_fn, kw, mode, min(many, n_strata), threads=nthreads, shrink=shrink)
         out["cpu_baseline_all_cores"] = {"value": round(cnt2["segments"] / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": nthreads,
-                                         "kind": "port", "sample": f"full frame, {max(args.cpu_strata, 8)} strata, OpenMP rows, {dt2:.1f} s"}
-        out["time_to_1000spp_cpu_1core_s"] = round(dt / args.cpu_strata * 1000.0, 1)
+                                         "kind": "port", "sample": f"{frame}, {min(many, n_strata)} strata, OpenMP rows, {dt2:.1f} s"}
+        out["time_to_1000spp_cpu_1core_s"] = round(dt / cpu_strata * 1000.0 * shrink * shrink, 1)
     # The path has no dense contraction and moves almost nothing through HBM: its roofline is
     # the fp32 vector peak.  achieved = algorithmic flops per segment (reference arithmetic,
     # FMA = 2, counted by the oracle) x segments per launch / the kernel's launch duration.

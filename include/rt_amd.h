@@ -166,12 +166,14 @@ typedef struct {
 
 #define RT_FLAG_TIME_KERNELS 1u /* bracket kernels with HIP events (see rt_stats) */
 #define RT_FLAG_WAVEFRONT 2u    /* ray-queue pipeline (scan/generate/extend/shade launches) instead of
-                                 * the persistent path kernel; same image for the same seed */
+                                 * the persistent path kernel; the same samples for the same seed (images equal
+                                 * up to the order of the film's fp32 additions, as between any two renders) */
 /* The persistent kernel has two variants.  Lane-bound: every lane carries one path from its camera
  * ray to its end.  Regrouping: every wave keeps a pool of paths in LDS and regroups them by the step
  * they wait for (closest hit, scatter at a diffuse / metal / glass vertex, end), so that each step runs
  * with most lanes active; behind a tree a lane keeps a traversal across turns and takes the next ray
- * from the pool when it is done.  Same image either way.  Default: regrouping on a flat world
+ * from the pool when it is done.  The same samples either way (the film's fp32 sums are added in
+ * whatever order the waves finish: two renders agree to the last bits, not bit for bit).  Default: regrouping on a flat world
  * (measured 40 % faster on the Book-3 Cornell box, 3 % on the main.rs scene) and behind trees of 8192
  * nodes or more (14 % faster on the 1 M-primitive scene, 2 % slower on the Book-1 scene's 232 nodes);
  * RT_FLAG_REGROUP asks for regrouping wherever it exists, RT_FLAG_NO_REGROUP for the lane-bound kernel.

@@ -20,6 +20,9 @@ struct EventPair {
     hipEvent_t a, b;
     int cls;
 };
+// Event pairs a handle keeps for timing launches: drained at every poll point of the ray-queue loop,
+// so a long render reuses a few dozen; the cap is for a caller that times everything and never polls.
+constexpr size_t EV_POOL_MAX = 4096;
 
 } // namespace
 
@@ -503,6 +506,7 @@ struct Timer {
     int begin(int cls) {
         if (!on) return -1;
         if (h->ev_used == h->ev_pool.size()) {
+            if (h->ev_pool.size() >= EV_POOL_MAX) return -1; // this launch goes untimed (and uncounted)
             EventPair p{};
             if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return -1;
             h->ev_pool.push_back(p);
@@ -518,14 +522,19 @@ struct Timer {
     }
 };
 
-void drain_timers(rt_handle *h) {
-    for (size_t i = 0; i < h->ev_used; ++i) {
+// Adds up the first `upto` event pairs (their launches are known to be complete) and hands them
+// back to the pool; pairs recorded later move to the front.
+void drain_timers(rt_handle *h, size_t upto) {
+    upto = std::min(upto, h->ev_used);
+    for (size_t i = 0; i < upto; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) == hipSuccess)
             h->stats.kernel_ms[h->ev_pool[i].cls] += ms;
     }
-    h->ev_used = 0;
+    std::rotate(h->ev_pool.begin(), h->ev_pool.begin() + upto, h->ev_pool.begin() + h->ev_used);
+    h->ev_used -= upto;
 }
+void drain_timers(rt_handle *h) { drain_timers(h, h->ev_used); }
 
 // One launch of the persistent path kernel: as many blocks as the device keeps resident.
 template <int MODE, int ACCEL>
@@ -1237,6 +1246,7 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     const int ITERS_PER_POLL = 8;
     int slot = 0;
     bool pending[2] = {false, false};
+    size_t ev_mark[2] = {0, 0}; // event pairs in use when each poll event was recorded
     bool done = false;
     unsigned long long guard = 0;
     const unsigned long long max_iters = total / (size_t(n_chunks) * cap) * (dc.max_depth + 1ull) + 4ull * dc.max_depth + 64;
@@ -1271,11 +1281,17 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
         RT_HIP(hipMemcpyAsync(&h->h_ctrl[slot], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
         RT_HIP(hipEventRecord(h->ev_poll[slot], h->stream));
         pending[slot] = true;
+        ev_mark[slot] = h->ev_used;
         // look at the previous batch while this one runs
         int prev = slot ^ 1;
         if (pending[prev]) {
             RT_HIP(hipEventSynchronize(h->ev_poll[prev]));
             pending[prev] = false;
+            // everything recorded before that poll event has finished: its timers go back to the pool
+            const size_t done_pairs = ev_mark[prev];
+            drain_timers(h, done_pairs);
+            ev_mark[slot] -= std::min(done_pairs, ev_mark[slot]);
+            ev_mark[prev] = 0;
             if (h->h_ctrl[prev].active == 0 && h->h_ctrl[prev].next_sample == total) done = true;
         }
         slot ^= 1;

@@ -477,29 +477,32 @@ __device__ __forceinline__ void trav4_begin(float thi, uint32_t &cur, uint32_t &
 // array (entry i at stack[i * stride]).  SPILL: only the first lds_entries entries live there, deeper
 // ones in global memory (entry i at spill[(i - lds_entries) * spill_stride]) -- for kernels that
 // need the LDS for something else; pushes beyond a handful of pending siblings are rare.
+// The two parts of a stack are named by address space, so that a push is an LDS store (and, behind
+// a rarely taken branch, a global store) instead of one generic store through a selected pointer.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(1))) uint32_t global_u32;
 struct TravMem {
-    uint32_t *stack;
-    uint32_t stride;
+    lds_u32 *stack;       // this lane's column: entry i at stack[i * STRIDE]
     const char *l_nodes;  // LDS copy of the first nodes
     uint32_t lds_bytes;   // of l_nodes
     uint32_t lds_entries; // SPILL only
-    uint32_t *spill;      // SPILL only: this lane's column
+    global_u32 *spill;    // SPILL only: this lane's column
     uint32_t spill_stride;
 };
 __device__ __forceinline__ TravMem block_trav_mem(SceneRef sc, uint32_t *s_dyn, uint32_t node_bytes) {
     // kernels whose whole dynamic LDS is [stack4][BLOCK] stack words followed by the staged nodes
-    return TravMem{s_dyn + threadIdx.x, uint32_t(BLOCK), reinterpret_cast<const char *>(s_dyn + size_t(sc.stack4) * BLOCK),
+    return TravMem{(lds_u32 *)(s_dyn + threadIdx.x), reinterpret_cast<const char *>(s_dyn + size_t(sc.stack4) * BLOCK),
                    sc.lds_nodes4 * node_bytes, 0u, nullptr, 0u};
 }
-template <bool SPILL> __device__ __forceinline__ void trav_push(const TravMem &m, uint32_t &sp, uint32_t v) {
-    if (!SPILL || sp < m.lds_entries) m.stack[sp * m.stride] = v;
-    else m.spill[(sp - m.lds_entries) * m.spill_stride] = v;
+template <bool SPILL, uint32_t STRIDE> __device__ __forceinline__ void trav_push(const TravMem &m, uint32_t &sp, uint32_t v) {
+    if (SPILL && __builtin_expect(sp >= m.lds_entries, 0)) m.spill[size_t(sp - m.lds_entries) * m.spill_stride] = v;
+    else m.stack[sp * STRIDE] = v;
     ++sp;
 }
-template <bool SPILL> __device__ __forceinline__ uint32_t trav_pop(const TravMem &m, uint32_t &sp) {
+template <bool SPILL, uint32_t STRIDE> __device__ __forceinline__ uint32_t trav_pop(const TravMem &m, uint32_t &sp) {
     --sp;
-    if (!SPILL || sp < m.lds_entries) return m.stack[sp * m.stride];
-    return m.spill[(sp - m.lds_entries) * m.spill_stride];
+    if (SPILL && __builtin_expect(sp >= m.lds_entries, 0)) return m.spill[size_t(sp - m.lds_entries) * m.spill_stride];
+    return m.stack[sp * STRIDE];
 }
 // QUANT: 64-byte nodes.  The child boxes are bytes on a grid of the node's own -- plane = origin +
 // q * 2^e per axis, lower planes rounded down and upper planes up by the builder (rt_accel.h), so a
@@ -600,7 +603,7 @@ key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                           
 #undef RT_CSWAP
 }
 
-template <bool STAGED, bool QUANT = false, bool SPILL = false>
+template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK>
 __device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
                                             const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best) {
     const RayConsts rcn = ray_consts(o, d);
@@ -615,13 +618,13 @@ __device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time,
         if (!at_node) continue;
         uint32_t key[4], ref[4];
         wide_node_visit<STAGED, QUANT>(sc, mem.l_nodes, mem.lds_bytes, rcn, tlo, best.t, cur, key, ref);
-        if (key[3] != 0xFFFFFFFFu) trav_push<SPILL>(mem, sp, ref[3]);
-        if (key[2] != 0xFFFFFFFFu) trav_push<SPILL>(mem, sp, ref[2]);
-        if (key[1] != 0xFFFFFFFFu) trav_push<SPILL>(mem, sp, ref[1]);
+        if (key[3] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[3]);
+        if (key[2] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[2]);
+        if (key[1] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[1]);
         if (key[0] != 0xFFFFFFFFu) {
             cur = ref[0];
         } else if (sp) {
-            cur = trav_pop<SPILL>(mem, sp);
+            cur = trav_pop<SPILL, STRIDE>(mem, sp);
         } else {
             cur = RT_REF_NONE;
         }
@@ -631,7 +634,7 @@ __device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time,
         const uint32_t before = best.ref;
         test_prim(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best);
         if (best.ref != before) best.cls = (cur & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
-        cur = sp ? trav_pop<SPILL>(mem, sp) : RT_REF_NONE;
+        cur = sp ? trav_pop<SPILL, STRIDE>(mem, sp) : RT_REF_NONE;
     }
 }
 
@@ -1888,8 +1891,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
     }
     const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
     TravPool &pool = pools[wave];
-    const TravMem mem{stacks + wave * POOL_STACK * WAVE + lane, uint32_t(WAVE), reinterpret_cast<const char *>(l_nodes),
-                      lds_nodes * NODE_BYTES, POOL_STACK, spill + (size_t(blockIdx.x) * BLOCK + threadIdx.x), gridDim.x * uint32_t(BLOCK)};
+    const TravMem mem{(lds_u32 *)(stacks + wave * POOL_STACK * WAVE + lane), reinterpret_cast<const char *>(l_nodes), lds_nodes * NODE_BYTES,
+                      POOL_STACK, (global_u32 *)(spill + (size_t(blockIdx.x) * BLOCK + threadIdx.x)), gridDim.x * uint32_t(BLOCK)};
     for (uint32_t i = lane; i < uint32_t(POOL_SLOTS); i += WAVE) pool.list[RG_FREE][i] = uint8_t(i);
     uint32_t n_free = POOL_SLOTS, n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0, n_end = 0; // list lengths, wave-uniform
     const unsigned long long total = ctrl->total_samples;
@@ -1976,9 +1979,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
             // 1. a traversal round for the lanes that hold a ray
             if (traversing) {
                 if (lds_nodes) // uniform
-                    trav4_round<true, QUANT, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+                    trav4_round<true, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
                 else
-                    trav4_round<false, QUANT, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+                    trav4_round<false, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
             }
             RT_RG_COUNT(RG_RAY, n_trav);
             RT_POOL_TICK(RG_RAY);
