@@ -365,25 +365,24 @@ int ensure_film(rt_handle *h, uint32_t w, uint32_t hgt) {
     return 0;
 }
 
-// Six parallelograms that are the faces of one rectangular box -- what box3 builds
-// (hittable.rs:398-455), under any rigid map: a frame, the two plane offsets per axis measured
-// from the centre, and the faces' refs by (axis, side).  Record layout: scan_flat.
-bool match_box(const rt_quad *const q[6], const uint32_t refs[6], float rec[32]) {
+// Parallelograms that are faces of one rectangular box -- what box3 builds (hittable.rs:398-455),
+// under any rigid map, and what the walls of a room are: a frame, the two plane offsets per axis
+// measured from the centre, and the faces' refs by (axis, side).  n = 6 faces, or 5 with one face
+// absent (RT_REF_NONE in its place: a room open towards the camera).  Every face present must span
+// the box in its two directions, so the absent face's plane follows from the others.  Record
+// layout: scan_flat.
+bool match_box(const rt_quad *const *q, const uint32_t *refs, int n, float rec[32]) {
+    if (n != 5 && n != 6) return false;
     typedef double D3[3];
     auto dot3 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
     auto len3 = [&](const double *a) { return std::sqrt(dot3(a, a)); };
-    D3 centre[6], c = {0, 0, 0};
     double extent = 0, reach = 0;
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < n; ++i) {
         if (q[i]->shape != RT_SHAPE_PARALLELOGRAM) return false;
         D3 u = {q[i]->u[0], q[i]->u[1], q[i]->u[2]}, v = {q[i]->v[0], q[i]->v[1], q[i]->v[2]};
         const double lu = len3(u), lv = len3(v);
         if (!(lu > 0 && lv > 0) || std::fabs(dot3(u, v)) > 1e-6 * lu * lv) return false; // a rectangle
-        for (int a = 0; a < 3; ++a) {
-            centre[i][a] = q[i]->q[a] + 0.5 * (u[a] + v[a]);
-            c[a] += centre[i][a] / 6.0;
-            reach = std::max(reach, std::fabs(double(q[i]->q[a])));
-        }
+        for (int a = 0; a < 3; ++a) reach = std::max(reach, std::fabs(double(q[i]->q[a])));
         extent = std::max(extent, std::max(lu, lv));
     }
     const double tol = 1e-5 * (extent + reach); // the records are fp32: corners carry ~1e-7 relative
@@ -396,61 +395,85 @@ bool match_box(const rt_quad *const q[6], const uint32_t refs[6], float rec[32])
         e[2][1] = e[0][2] * e[1][0] - e[0][0] * e[1][2];
         e[2][2] = e[0][0] * e[1][1] - e[0][1] * e[1][0];
     }
-    double plane[3][2], span[3][2][2];
-    bool seen[3][2] = {};
-    uint32_t face_ref[3][2];
-    for (int i = 0; i < 6; ++i) {
-        D3 m = {centre[i][0] - c[0], centre[i][1] - c[1], centre[i][2] - c[2]};
-        double along[3];
+    // every face in the frame: the axis of its normal, its plane there, its extent on the two other axes
+    int axis[6];
+    double plane[6], lo_of[6][3], hi_of[6][3];
+    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n; ++i) {
+        D3 nrm = {q[i]->n[0], q[i]->n[1], q[i]->n[2]};
         int k = 0;
-        for (int a = 0; a < 3; ++a) {
-            along[a] = dot3(m, e[a]);
-            if (std::fabs(along[a]) > std::fabs(along[k])) k = a;
+        for (int a = 1; a < 3; ++a)
+            if (std::fabs(dot3(nrm, e[a])) > std::fabs(dot3(nrm, e[k]))) k = a;
+        if (std::fabs(std::fabs(dot3(nrm, e[k])) - 1.0) > 1e-6) return false;
+        axis[i] = k;
+        for (int a = 0; a < 3; ++a) lo_of[i][a] = 1e300, hi_of[i][a] = -1e300;
+        for (int c = 0; c < 4; ++c) {
+            D3 p;
+            for (int a = 0; a < 3; ++a) p[a] = double(q[i]->q[a]) + ((c & 1) ? double(q[i]->u[a]) : 0.0) + ((c & 2) ? double(q[i]->v[a]) : 0.0);
+            for (int a = 0; a < 3; ++a) {
+                const double x = dot3(p, e[a]);
+                lo_of[i][a] = std::min(lo_of[i][a], x), hi_of[i][a] = std::max(hi_of[i][a], x);
+            }
         }
-        const int side = along[k] > 0 ? 1 : 0;
-        if (seen[k][side] || std::fabs(along[k]) <= tol) return false;
-        for (int a = 0; a < 3; ++a)
-            if (a != k && std::fabs(along[a]) > tol) return false; // the face is centred on its axis
-        D3 n = {q[i]->n[0], q[i]->n[1], q[i]->n[2]};
-        if (std::fabs(std::fabs(dot3(n, e[k])) - 1.0) > 1e-6) return false;
-        // its edges run along the two other axes
-        D3 u = {q[i]->u[0], q[i]->u[1], q[i]->u[2]}, v = {q[i]->v[0], q[i]->v[1], q[i]->v[2]};
-        const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
-        const double u1 = std::fabs(dot3(u, e[a1])), u2 = std::fabs(dot3(u, e[a2]));
-        const double v1 = std::fabs(dot3(v, e[a1])), v2 = std::fabs(dot3(v, e[a2]));
-        const bool u_on_1 = u1 >= u2;
-        if ((u_on_1 ? u2 : u1) > tol || (u_on_1 ? v1 : v2) > tol) return false;
-        span[k][side][0] = u_on_1 ? u1 : v1; // extent along a1
-        span[k][side][1] = u_on_1 ? v2 : u2; // extent along a2
-        D3 rel = {q[i]->q[0] - c[0], q[i]->q[1] - c[1], q[i]->q[2] - c[2]};
-        plane[k][side] = dot3(rel, e[k]); // a point of the face's own plane
-        seen[k][side] = true;
-        face_ref[k][side] = refs[i];
+        if (hi_of[i][k] - lo_of[i][k] > tol) return false; // its edges run along the two other axes
+        plane[i] = 0.5 * (lo_of[i][k] + hi_of[i][k]);
+        for (int a = 0; a < 3; ++a) blo[a] = std::min(blo[a], lo_of[i][a]), bhi[a] = std::max(bhi[a], hi_of[i][a]);
     }
-    for (int k = 0; k < 3; ++k) {
-        if (!seen[k][0] || !seen[k][1] || !(plane[k][0] < plane[k][1])) return false;
-        const int a1 = (k + 1) % 3, a2 = (k + 2) % 3;
-        for (int side = 0; side < 2; ++side) // every face spans the box in its two directions
-            if (std::fabs(span[k][side][0] - (plane[a1][1] - plane[a1][0])) > 2 * tol ||
-                std::fabs(span[k][side][1] - (plane[a2][1] - plane[a2][0])) > 2 * tol)
-                return false;
+    bool seen[3][2] = {};
+    int face_at[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+    for (int i = 0; i < n; ++i) {
+        const int k = axis[i];
+        if (!(bhi[k] - blo[k] > 2 * tol)) return false;
+        const int side = std::fabs(plane[i] - blo[k]) <= tol ? 0 : (std::fabs(plane[i] - bhi[k]) <= tol ? 1 : -1);
+        if (side < 0 || seen[k][side]) return false;
+        for (int a = 0; a < 3; ++a) // the face spans the box in its two directions
+            if (a != k && (std::fabs(lo_of[i][a] - blo[a]) > 2 * tol || std::fabs(hi_of[i][a] - bhi[a]) > 2 * tol)) return false;
+        seen[k][side] = true;
+        face_at[k][side] = i;
     }
     std::fill(rec, rec + 32, 0.0f);
+    double c[3] = {0, 0, 0}; // the centre, in world coordinates
+    for (int k = 0; k < 3; ++k)
+        for (int a = 0; a < 3; ++a) c[a] += 0.5 * (blo[k] + bhi[k]) * e[k][a];
+    const uint32_t none = RT_REF_NONE;
     for (int k = 0; k < 3; ++k) {
         for (int a = 0; a < 3; ++a) rec[3 * k + a] = float(e[k][a]);
         rec[9 + k] = float(c[k]);
-        std::memcpy(&rec[18 + k], &face_ref[k][0], 4);
-        std::memcpy(&rec[21 + k], &face_ref[k][1], 4);
+        std::memcpy(&rec[18 + k], face_at[k][0] >= 0 ? &refs[face_at[k][0]] : &none, 4);
+        std::memcpy(&rec[21 + k], face_at[k][1] >= 0 ? &refs[face_at[k][1]] : &none, 4);
     }
-    // offsets from the centre as fp32 stores it, along the frame as fp32 stores it
+    // offsets from the centre as fp32 stores it, along the frame as fp32 stores it: a face's own
+    // plane from its own quad record, an absent face's from the box
     for (int k = 0; k < 3; ++k)
         for (int side = 0; side < 2; ++side) {
-            const int i = int(std::find(refs, refs + 6, face_ref[k][side]) - refs);
             double off = 0;
-            for (int a = 0; a < 3; ++a) off += (double(q[i]->q[a]) - double(rec[9 + a])) * double(rec[3 * k + a]);
+            const int i = face_at[k][side];
+            if (i >= 0) {
+                for (int a = 0; a < 3; ++a) off += (double(q[i]->q[a]) - double(rec[9 + a])) * double(rec[3 * k + a]);
+            } else {
+                double cc = 0;
+                for (int a = 0; a < 3; ++a) cc += double(rec[9 + a]) * double(rec[3 * k + a]);
+                off = (side ? bhi[k] : blo[k]) - cc;
+            }
             rec[(side ? 15 : 12) + k] = float(off);
         }
     return true;
+}
+
+// Would recognising these quads as a box change which primitive a tie goes to?  HittableVec::hit
+// gives a tie to the later primitive (t <= closest); the scan tests the remaining quads first and
+// the boxes after them, in list order.  That is the list's own order unless a remaining quad that
+// comes after the box in the list lies in the plane of one of its faces.
+bool quad_in_a_face_plane(const rt_quad &other, const rt_quad *const *faces, int n) {
+    for (int i = 0; i < n; ++i) {
+        const rt_quad &f = *faces[i];
+        const double nn = double(other.n[0]) * f.n[0] + double(other.n[1]) * f.n[1] + double(other.n[2]) * f.n[2];
+        if (std::fabs(std::fabs(nn) - 1.0) > 1e-6) continue;
+        double d = 0, scale = 1.0;
+        for (int a = 0; a < 3; ++a) d += (double(other.q[a]) - f.q[a]) * f.n[a], scale = std::max(scale, std::fabs(double(f.q[a])));
+        if (std::fabs(d) <= 1e-5 * scale) return true;
+    }
+    return false;
 }
 
 // A sphere of a flat world that nothing else reaches into: every other primitive of the list
@@ -853,18 +876,37 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
                     flat_quad_refs.push_back(r);
                 }
                 // Boxes at the end of the quads (main.rs:52-69 lists walls, light, boxes) leave the
-                // quad records for one slab test each.  Only from the end: the scan takes quads
-                // first, then boxes, and a later quad wins a tie (a box standing on the floor).
+                // quad records for one slab test each.  From the end: the scan takes quads first, then
+                // boxes, and a later quad wins a tie (a box standing on the floor).
                 std::vector<float> found;
                 while (flat_quad_refs.size() >= 6) {
                     const size_t first = flat_quad_refs.size() - 6;
                     const rt_quad *faces[6];
                     for (int i = 0; i < 6; ++i) faces[i] = &s->quads[flat_quad_refs[first + i] & RT_REF_INDEX_MASK];
                     float rec[32];
-                    if (!match_box(faces, &flat_quad_refs[first], rec)) break;
+                    if (!match_box(faces, &flat_quad_refs[first], 6, rec)) break;
                     found.insert(found.begin(), rec, rec + 32);
                     flat_quad_refs.resize(first);
                     flat_quads.resize(first * 16);
+                }
+                // A room: the quads the list starts with, when they are five or six faces of one box (the
+                // walls of cornell_box.toml; the side towards the camera is open).  It is tested with the
+                // boxes, before them as in the list; that keeps the list's tie order as long as no quad that
+                // stays a quad lies in the plane of a wall.
+                for (int n_faces = 6; n_faces >= 5; --n_faces) {
+                    if (flat_quad_refs.size() < size_t(n_faces)) continue;
+                    const rt_quad *faces[6];
+                    for (int i = 0; i < n_faces; ++i) faces[i] = &s->quads[flat_quad_refs[i] & RT_REF_INDEX_MASK];
+                    float rec[32];
+                    if (!match_box(faces, flat_quad_refs.data(), n_faces, rec)) continue;
+                    bool tie_order_kept = true;
+                    for (size_t j = n_faces; j < flat_quad_refs.size(); ++j)
+                        if (quad_in_a_face_plane(s->quads[flat_quad_refs[j] & RT_REF_INDEX_MASK], faces, n_faces)) tie_order_kept = false;
+                    if (!tie_order_kept) break;
+                    found.insert(found.begin(), rec, rec + 32);
+                    flat_quad_refs.erase(flat_quad_refs.begin(), flat_quad_refs.begin() + n_faces);
+                    flat_quads.erase(flat_quads.begin(), flat_quads.begin() + size_t(n_faces) * 16);
+                    break;
                 }
                 flat_boxes = found;
                 const std::vector<uint32_t> list(s->refs + s->nodes[ri].left, s->refs + s->nodes[ri].left + s->nodes[ri].count);

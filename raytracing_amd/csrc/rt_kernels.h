@@ -781,14 +781,15 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
         const float t_near = fmaxf(fmaxf(t_lo[0], t_lo[1]), t_lo[2]), t_far = fminf(fminf(t_hi[0], t_hi[1]), t_hi[2]);
         const uint32_t near_ref = t_lo[0] >= fmaxf(t_lo[1], t_lo[2]) ? r_in[0] : (t_lo[1] >= t_lo[2] ? r_in[1] : r_in[2]);
         const uint32_t far_ref = t_hi[0] <= fminf(t_hi[1], t_hi[2]) ? r_out[0] : (t_hi[1] <= t_hi[2] ? r_out[1] : r_out[2]);
-        const bool use_near = (t_near >= tlo) & (near_ref != origin_ref);
+        // (a face may be absent -- a room open on one side: RT_REF_NONE, never a hit)
+        const bool use_near = (t_near >= tlo) & (near_ref != origin_ref) & (near_ref != RT_REF_NONE);
         const float tc = use_near ? t_near : t_far;
         const uint32_t rcand = use_near ? near_ref : far_ref;
         // A later quad wins a tie (t <= closest, hittable.rs:252-264), and ties happen: a box
         // stands on the floor, its bottom face in the floor's plane.  The quad records give such
         // a pair the same t to the bit; the slab arithmetic differs from theirs in the last
         // bits, so the tie is taken within 4 ulp.
-        const bool ok = (t_near <= t_far) & (tc >= tlo) & (tc <= best.t * (1.0f + 0x1p-21f)) & (rcand != origin_ref);
+        const bool ok = (t_near <= t_far) & (tc >= tlo) & (tc <= best.t * (1.0f + 0x1p-21f)) & (rcand != origin_ref) & (rcand != RT_REF_NONE);
         best.t = ok ? tc : best.t;
         best.ref = ok ? rcand : best.ref;
     }

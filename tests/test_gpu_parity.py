@@ -489,6 +489,43 @@ def test_image_textured_quads_in_a_flat_world(device, pipeline):
     assert same.mean() > 0.5 and np.abs(u[same] - u2[same]).max() < 1e-4 and np.abs(v[same] - v2[same]).max() < 1e-4
 
 
+def test_cornell_walls_are_recognised_as_a_room(device):
+    """The five walls cornell_box.toml starts the world with are faces of one box whose side towards
+    the camera is absent: the flat scan tests them as one box (the ray leaves through the face it
+    would have hit as a quad; an absent face is never hit).  A quad lying in a wall's plane later in
+    the list would take ties from it in HittableVec::hit, so then the walls stay quads."""
+    for name, boxes in (("c1", 3), ("c3", 2)):
+        scene(name, device)
+        info = device.accel_info()
+        assert info["kind"] == "flat" and info["flat_boxes"] == boxes and info["flat_quads"] == 1, info  # the lamp stays a quad
+    # through the open side from outside, out through it from inside, and onto the outside of a wall
+    o = np.float32([[278, 278, -800], [400, 450, 100], [-100, 278, 278], [278, 278, 300], [278, 900, 278]])
+    d = np.float32([[0, 0, 1], [0.2, 0.1, -1], [1, 0, 0], [0, -1, 0.2], [0, -1, 0]])
+    scene("c1", device)
+    hit, prim, t, _, _ = device.intersect_batch(o, d, np.zeros(5, np.float32))
+    host, osb, cam, mode, _ = scene("c1", device)
+    h2, p2, t2, *_ = orc.intersect_batch(osb, o, d, np.zeros(5))
+    assert hit.tolist() == h2.tolist() == [1, 0, 1, 1, 1] and prim.tolist() == p2.tolist()
+    assert np.allclose(t[hit == 1], t2[h2 == 1], rtol=1e-5)
+    # a poster on the back wall: it lies in the wall's plane and comes later in the list
+    host2, osb2 = ra.SceneBuilder(), orc.scene()
+    from oracle import config_oracle
+    for sb, kw in ((host2, {}), (osb2, dict(toml_objects=config_oracle.toml_objects))):
+        objs = [sb.load_toml(ra.scenes.cornell_toml_text())] if not kw else list(config_oracle.toml_objects(sb, ra.scenes.cornell_toml_text()))
+        poster = sb.quad((100.0, 100.0, 555.0), (200.0, 0.0, 0.0), (0.0, 200.0, 0.0), sb.lambertian((0.9, 0.1, 0.1)))
+        lamp = sb.quad((343.0, 554.0, 332.0), (-130.0, 0.0, 0.0), (0.0, 0.0, -105.0), sb.light((20.0, 20.0, 20.0)))
+        sb.set_world(sb.list(objs + [poster, lamp]))
+        sb.set_lights(lamp)
+    device.upload(host2)
+    info = device.accel_info()
+    assert info["flat_boxes"] == 0 and info["flat_quads"] == 7, info
+    o = np.float32([[200, 200, 100]] * 2)
+    d = np.float32([[0, 0, 1], [0.4, 0, 1]])  # onto the poster (it wins the tie with the wall), and beside it
+    hit, prim, t, _, _ = device.intersect_batch(o, d, np.zeros(2, np.float32))
+    h2, p2, t2, *_ = orc.intersect_batch(osb2, o, d, np.zeros(2))
+    assert prim.tolist() == p2.tolist() == [5, 4] and np.allclose(t, t2, rtol=1e-6)
+
+
 def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device):
     """A flat world's trailing box3 runs take one slab test per box.  The hits are the quad
     tests' hits: a world with its boxes last (recognised) and the same world with a quad moved
