@@ -61,9 +61,9 @@ FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path dep
 FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0, "c2": 1310.7, "c4": 1248.7, "c5": 9525.6}
 # HBM-side bytes per segment of the persistent kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
 # WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments), keyed by
-# (workload, regrouping variant): profiles/r1h_pmc_c3_spp64_regroup.txt and
+# (workload, regrouping variant): profiles/r2_pmc_c3_spp64.txt and
 # profiles/r1g_pmc_c3_spp64_persistent.txt.  Not collected live: counters need their own runs.
-PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 510 + 4073925) * 1024 / 861.4e6,
+PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 498 + 4073518) * 1024 / 861.4e6,
                          ("c3", False): (2 * 12796 + 4905618) * 1024 / 861.4e6}
 
 
@@ -159,8 +159,19 @@ def main():
     extra = dict(wavefront=True, pool_size=args.pool, time_every=8) if args.wavefront else {}
     if args.regroup != "auto":
         extra["regroup"] = args.regroup == "on"
-    for _ in range(args.warmup):
+    last_note = [time.perf_counter()]
+
+    def note(what):
+        # frames of the large workloads take a minute each: say so on stderr now and then, so that
+        # a harness watching for output does not take the run for hung
+        now = time.perf_counter()
+        if rank == 0 and now - last_note[0] > 20.0:
+            print(f"[bench] {what}", file=sys.stderr, flush=True)
+            last_note[0] = now
+
+    for w in range(args.warmup):
         renderer.render(rcam, n_strata, rank, world, mode, seed=1, **extra)
+        note(f"warmup step {w + 1} of {args.warmup} done")
     barrier()
     seg = 0
     kernel_ms = np.zeros(5)
@@ -181,6 +192,7 @@ def main():
             kernel_ms += np.array(st.kernel_ms)
             timed += np.array(st.timed_launches)
             launches += np.array(st.launches)
+        note(f"step {step + 1} of {args.steps} done")
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -224,7 +236,11 @@ def main():
         "kernel_ms_per_step": {n: round(float(per_launch_ms[i] * launches[i]) / args.steps, 3) for i, n in enumerate(names)},
     }
     # ray-queue / film traffic of the dominant kernel against HBM (the secondary roofline)
-    hbm = {"bound": "hbm", "kernel": "k_paths_regroup" if (names[k] == "paths" and regrouped) else "k_" + names[k], "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
+    # the regrouping variant of the persistent kernel is k_paths_regroup on a flat world and
+    # k_paths_pool behind a tree
+    flat_world = dev.accel_info()["kind"] == "flat"
+    paths_kernel = ("k_paths_regroup" if flat_world else "k_paths_pool") if regrouped else "k_paths"
+    hbm = {"bound": "hbm", "kernel": paths_kernel if names[k] == "paths" else "k_" + names[k], "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
            "bytes_per_segment": round(bytes_per_seg, 1), "segments_per_launch": int(seg_per_launch),
            "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]), "timed_launches": int(timed[k])}
@@ -247,7 +263,7 @@ def main():
     # the fp32 vector peak.  achieved = algorithmic flops per segment (reference arithmetic,
     # FMA = 2, counted by the oracle) x segments per launch / the kernel's launch duration.
     if fps:
-        kernel_name = "k_paths_regroup" if (names[k] == "paths" and regrouped) else "k_" + names[k]
+        kernel_name = paths_kernel if names[k] == "paths" else "k_" + names[k]
         tflops = fps * seg_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         if names[k] != "paths":
             # a segment's arithmetic is spread over the four wavefront kernels: price them together
