@@ -247,10 +247,15 @@ typedef struct {
     double cost;            /* wide only: expected box tests of a random ray through the root box */
     uint32_t flat_quads;    /* flat only: quads tested one by one */
     uint32_t flat_boxes;    /* flat only: runs of six quads at the end of the list that are the faces of one
-                             * rectangular box (box3, hittable.rs:398-455) and take one slab test each */
+                             * rectangular box (box3, hittable.rs:398-455), and the five or six walls of a
+                             * room the list starts with; they take one slab test each */
     uint32_t flat_alone_spheres; /* flat only: spheres that no other primitive of the list reaches into; the
                              * regrouping kernel knows where a ray going into one of them ends */
     uint32_t node_bytes;    /* size of a node of the structure searched (wide: 64 quantised, 128 fp32 boxes) */
+    uint32_t flat_boxes_aligned; /* of flat_boxes: along the three world axes (the walls of a room) */
+    uint32_t flat_boxes_upright; /* of flat_boxes: one axis the world's y, as under RotateY and Translate
+                             * (hittable.rs:760-1001); the slab test skips the dot products such axes
+                             * do not need.  Both are 0 when the list orders its boxes otherwise. */
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 /* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it

@@ -371,7 +371,7 @@ int ensure_film(rt_handle *h, uint32_t w, uint32_t hgt) {
 // absent (RT_REF_NONE in its place: a room open towards the camera).  Every face present must span
 // the box in its two directions, so the absent face's plane follows from the others.  Record
 // layout: scan_flat.
-bool match_box(const rt_quad *const *q, const uint32_t *refs, int n, float rec[32]) {
+bool match_box(const rt_quad *const *q, const uint32_t *refs, int n, float rec[32], bool general_frame = false) {
     if (n != 5 && n != 6) return false;
     typedef double D3[3];
     auto dot3 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
@@ -431,32 +431,71 @@ bool match_box(const rt_quad *const *q, const uint32_t *refs, int n, float rec[3
         seen[k][side] = true;
         face_at[k][side] = i;
     }
+    // The frame in canonical form.  Every rigid map of the reference is a RotateY and a Translate, so
+    // one axis of a box is the world's y and the two others lie in the xz plane ("upright"); the
+    // walls of a room are along all three world axes ("aligned").  Exact tests on the fp32 frame: a
+    // frame that only nearly qualifies stays general.  Reordering axes and reversing one (its lo
+    // and hi faces change places) leave the box what it is.
+    auto unit_along = [&](int k, int w) { // +-1 when fp32(e[k]) is exactly +-the world axis w, else 0
+        for (int a = 0; a < 3; ++a) {
+            const float v = float(e[k][a]);
+            if (a == w ? std::fabs(v) != 1.0f : v != 0.0f) return 0;
+        }
+        return e[k][w] > 0 ? 1 : -1;
+    };
+    int order[3] = {0, 1, 2}, sign[3] = {1, 1, 1};
+    uint32_t cls = RT_BOX_GENERAL;
+    for (int ky = 0; ky < 3 && cls == RT_BOX_GENERAL && !general_frame; ++ky) {
+        if (!unit_along(ky, 1)) continue;
+        int k0 = (ky + 1) % 3, k2 = (ky + 2) % 3;
+        if (float(e[k0][1]) != 0.0f || float(e[k2][1]) != 0.0f) continue;
+        cls = RT_BOX_UPRIGHT;
+        if (unit_along(k0, 2) && unit_along(k2, 0)) std::swap(k0, k2);
+        order[0] = k0, order[1] = ky, order[2] = k2;
+        sign[1] = unit_along(ky, 1);
+        if (unit_along(k0, 0) && unit_along(k2, 2)) cls = RT_BOX_ALIGNED, sign[0] = unit_along(k0, 0), sign[2] = unit_along(k2, 2);
+    }
+    double ce[3][3], clo[3], chi[3];
+    int cface[3][2];
+    for (int j = 0; j < 3; ++j) {
+        const int k = order[j];
+        for (int a = 0; a < 3; ++a) ce[j][a] = sign[j] * e[k][a];
+        clo[j] = sign[j] > 0 ? blo[k] : -bhi[k], chi[j] = sign[j] > 0 ? bhi[k] : -blo[k];
+        cface[j][0] = face_at[k][sign[j] > 0 ? 0 : 1], cface[j][1] = face_at[k][sign[j] > 0 ? 1 : 0];
+    }
     std::fill(rec, rec + 32, 0.0f);
     double c[3] = {0, 0, 0}; // the centre, in world coordinates
-    for (int k = 0; k < 3; ++k)
-        for (int a = 0; a < 3; ++a) c[a] += 0.5 * (blo[k] + bhi[k]) * e[k][a];
+    for (int j = 0; j < 3; ++j)
+        for (int a = 0; a < 3; ++a) c[a] += 0.5 * (clo[j] + chi[j]) * ce[j][a];
     const uint32_t none = RT_REF_NONE;
-    for (int k = 0; k < 3; ++k) {
-        for (int a = 0; a < 3; ++a) rec[3 * k + a] = float(e[k][a]);
-        rec[9 + k] = float(c[k]);
-        std::memcpy(&rec[18 + k], face_at[k][0] >= 0 ? &refs[face_at[k][0]] : &none, 4);
-        std::memcpy(&rec[21 + k], face_at[k][1] >= 0 ? &refs[face_at[k][1]] : &none, 4);
+    for (int j = 0; j < 3; ++j) {
+        for (int a = 0; a < 3; ++a) rec[3 * j + a] = float(ce[j][a]);
+        rec[9 + j] = float(c[j]);
+        std::memcpy(&rec[18 + j], cface[j][0] >= 0 ? &refs[cface[j][0]] : &none, 4);
+        std::memcpy(&rec[21 + j], cface[j][1] >= 0 ? &refs[cface[j][1]] : &none, 4);
     }
-    // offsets from the centre as fp32 stores it, along the frame as fp32 stores it: a face's own
-    // plane from its own quad record, an absent face's from the box
-    for (int k = 0; k < 3; ++k)
+    std::memcpy(&rec[24], &cls, 4);
+    // Planes, (lo, hi) per axis.  Along a world axis: the world coordinate, for a face present the
+    // one its own quad record holds (the scan then repeats the quad test's arithmetic).  Along any
+    // other axis: offsets from the centre as fp32 stores it, along the frame as fp32 stores it, a
+    // face's own plane from its own quad record.  An absent face's plane comes from the box.
+    for (int j = 0; j < 3; ++j) {
+        const bool world_axis = cls == RT_BOX_ALIGNED || (cls == RT_BOX_UPRIGHT && j == 1);
         for (int side = 0; side < 2; ++side) {
-            double off = 0;
-            const int i = face_at[k][side];
-            if (i >= 0) {
-                for (int a = 0; a < 3; ++a) off += (double(q[i]->q[a]) - double(rec[9 + a])) * double(rec[3 * k + a]);
+            double plane_at = 0;
+            const int i = cface[j][side];
+            if (world_axis) {
+                plane_at = i >= 0 ? double(q[i]->q[j]) : (side ? chi[j] : clo[j]);
+            } else if (i >= 0) {
+                for (int a = 0; a < 3; ++a) plane_at += (double(q[i]->q[a]) - double(rec[9 + a])) * double(rec[3 * j + a]);
             } else {
                 double cc = 0;
-                for (int a = 0; a < 3; ++a) cc += double(rec[9 + a]) * double(rec[3 * k + a]);
-                off = (side ? bhi[k] : blo[k]) - cc;
+                for (int a = 0; a < 3; ++a) cc += double(rec[9 + a]) * double(rec[3 * j + a]);
+                plane_at = (side ? chi[j] : clo[j]) - cc;
             }
-            rec[(side ? 15 : 12) + k] = float(off);
+            rec[12 + 2 * j + side] = float(plane_at);
         }
+    }
     return true;
 }
 
@@ -847,6 +886,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     // A world that is one list of primitives takes the stack-free scan: its quads packed in
     // list order for scalar loads, everything else by reference.
     std::vector<float> flat_quads, flat_boxes;
+    uint32_t n_boxes_aligned = 0, n_boxes_upright = 0;
     std::vector<uint32_t> flat_other, flat_quad_refs;
     // device copy of the spheres: pad = 1 marks a sphere of a flat world that nothing reaches into
     std::vector<rt_sphere> spheres(s->spheres, s->spheres + s->n_spheres);
@@ -878,14 +918,20 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
                 // Boxes at the end of the quads (main.rs:52-69 lists walls, light, boxes) leave the
                 // quad records for one slab test each.  From the end: the scan takes quads first, then
                 // boxes, and a later quad wins a tie (a box standing on the floor).
-                std::vector<float> found;
+                struct BoxFaces {
+                    const rt_quad *faces[6];
+                    uint32_t refs[6];
+                    int n;
+                };
+                std::vector<BoxFaces> found; // in list order
                 while (flat_quad_refs.size() >= 6) {
                     const size_t first = flat_quad_refs.size() - 6;
-                    const rt_quad *faces[6];
-                    for (int i = 0; i < 6; ++i) faces[i] = &s->quads[flat_quad_refs[first + i] & RT_REF_INDEX_MASK];
+                    BoxFaces b;
+                    b.n = 6;
+                    for (int i = 0; i < 6; ++i) b.refs[i] = flat_quad_refs[first + i], b.faces[i] = &s->quads[b.refs[i] & RT_REF_INDEX_MASK];
                     float rec[32];
-                    if (!match_box(faces, &flat_quad_refs[first], 6, rec)) break;
-                    found.insert(found.begin(), rec, rec + 32);
+                    if (!match_box(b.faces, b.refs, 6, rec)) break;
+                    found.insert(found.begin(), b);
                     flat_quad_refs.resize(first);
                     flat_quads.resize(first * 16);
                 }
@@ -895,20 +941,43 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
                 // stays a quad lies in the plane of a wall.
                 for (int n_faces = 6; n_faces >= 5; --n_faces) {
                     if (flat_quad_refs.size() < size_t(n_faces)) continue;
-                    const rt_quad *faces[6];
-                    for (int i = 0; i < n_faces; ++i) faces[i] = &s->quads[flat_quad_refs[i] & RT_REF_INDEX_MASK];
+                    BoxFaces b;
+                    b.n = n_faces;
+                    for (int i = 0; i < n_faces; ++i) b.refs[i] = flat_quad_refs[i], b.faces[i] = &s->quads[b.refs[i] & RT_REF_INDEX_MASK];
                     float rec[32];
-                    if (!match_box(faces, flat_quad_refs.data(), n_faces, rec)) continue;
+                    if (!match_box(b.faces, b.refs, n_faces, rec)) continue;
                     bool tie_order_kept = true;
                     for (size_t j = n_faces; j < flat_quad_refs.size(); ++j)
-                        if (quad_in_a_face_plane(s->quads[flat_quad_refs[j] & RT_REF_INDEX_MASK], faces, n_faces)) tie_order_kept = false;
+                        if (quad_in_a_face_plane(s->quads[flat_quad_refs[j] & RT_REF_INDEX_MASK], b.faces, n_faces)) tie_order_kept = false;
                     if (!tie_order_kept) break;
-                    found.insert(found.begin(), rec, rec + 32);
+                    found.insert(found.begin(), b);
                     flat_quad_refs.erase(flat_quad_refs.begin(), flat_quad_refs.begin() + n_faces);
                     flat_quads.erase(flat_quads.begin(), flat_quads.begin() + size_t(n_faces) * 16);
                     break;
                 }
-                flat_boxes = found;
+                // The scan runs the box classes one after the other (aligned, upright, general), and
+                // between boxes too a later one wins a tie.  When the list's own order is another, every
+                // box keeps a general frame and the list's order.
+                for (int pass = 0; pass < 2; ++pass) {
+                    flat_boxes.clear();
+                    n_boxes_aligned = n_boxes_upright = 0;
+                    bool in_class_order = true;
+                    uint32_t last = RT_BOX_ALIGNED;
+                    for (const BoxFaces &b : found) {
+                        float rec[32];
+                        if (!match_box(b.faces, b.refs, b.n, rec, pass == 1)) {
+                            fail(h, "upload: a recognised box no longer matches");
+                            return rollback();
+                        }
+                        uint32_t cls;
+                        std::memcpy(&cls, &rec[24], 4);
+                        if (cls > last) in_class_order = false;
+                        last = cls;
+                        n_boxes_aligned += cls == RT_BOX_ALIGNED, n_boxes_upright += cls == RT_BOX_UPRIGHT;
+                        flat_boxes.insert(flat_boxes.end(), rec, rec + 32);
+                    }
+                    if (in_class_order) break;
+                }
                 const std::vector<uint32_t> list(s->refs + s->nodes[ri].left, s->refs + s->nodes[ri].left + s->nodes[ri].count);
                 for (uint32_t r : list)
                     if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE && sphere_is_alone(s, list, r)) spheres[r & RT_REF_INDEX_MASK].pad = 1;
@@ -1000,6 +1069,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     flat_quads.resize((size_t(d.n_flat_quads) + 3) / 2 * 2 * 16, 0.0f);
     d.n_flat_other = uint32_t(flat_other.size());
     d.n_flat_boxes = uint32_t(flat_boxes.size() / 32);
+    d.n_flat_boxes_aligned = n_boxes_aligned, d.n_flat_boxes_upright = n_boxes_upright;
     if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, spheres.data(), spheres.size(), &ds) ||
         upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || (h->accel == ACCEL_BVH4Q ? upload(h, nodes4q.data(), nodes4q.size(), &dn4q) : upload(h, nodes4.data(), nodes4.size(), &dn4)) ||
@@ -1081,7 +1151,7 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
     if (out) {
         out->kind = uint32_t(ACCEL_BVH4);
         out->nodes = st.nodes, out->depth = st.depth, out->stack_entries = st.stack_need, out->cost = st.cost;
-        out->flat_quads = out->flat_boxes = out->flat_alone_spheres = 0;
+        out->flat_quads = out->flat_boxes = out->flat_alone_spheres = out->flat_boxes_aligned = out->flat_boxes_upright = 0;
         out->node_bytes = uint32_t(sizeof(Node4Q));
         std::vector<Node4Q> q;
         accel::quantise_nodes(nodes, q);
@@ -1104,6 +1174,8 @@ int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     out->flat_quads = h->accel == ACCEL_FLAT ? h->sc.n_flat_quads : 0u;
     out->flat_boxes = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes : 0u;
     out->flat_alone_spheres = h->alone_spheres;
+    out->flat_boxes_aligned = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_aligned : 0u;
+    out->flat_boxes_upright = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_upright : 0u;
     return 0;
 }
 

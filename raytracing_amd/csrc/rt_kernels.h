@@ -72,9 +72,13 @@ struct DScene {
     // (quantised boxes)
     const float4 *nodes4;
     uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_pairs, n_flat_other, n_nodes4, n_flat_boxes;
+    uint32_t n_flat_boxes_aligned, n_flat_boxes_upright; // the box records' first two classes (scan_flat)
     // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
     uint32_t stack4, lds_nodes4;
 };
+
+// how much of a flat world's box frame is the world's own (the class word of a box record, scan_flat)
+enum : uint32_t { RT_BOX_GENERAL = 0, RT_BOX_UPRIGHT = 1, RT_BOX_ALIGNED = 2 };
 
 // which structure a kernel instance searches
 // ACCEL_BVH4Q: the 4-wide tree with 64-byte nodes whose child boxes are 8-bit offsets on a grid of
@@ -757,41 +761,80 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
         }
     }
     // Boxes: six parallelograms that are the faces of one rectangular box cost one slab test in
-    // the box's frame (~65 vector instructions) instead of three pairs (135).  The ray crosses the
+    // the box's frame instead of three pairs (135 vector instructions).  The ray crosses the
     // faces' planes where the six quad tests put their hits -- t = (plane - e.o) / (e.d) with the
     // face normal +-e -- and of a convex box only the first crossing past tlo can be the closest
     // hit: the entry face, or the exit face for a ray that starts inside or on the entry face.
-    //   record, 32 floats: frame e0 e1 e2, centre c, plane offsets lo[3] hi[3] (along e_k, from c),
-    //   refs of the lo faces [3] and of the hi faces [3]
+    //   record, 32 floats: frame e0 e1 e2, centre c, planes (lo, hi) per axis, refs of the lo
+    //   faces [3] and of the hi faces [3], class
+    // The class says how much of the frame is the world's own (the upload brings the frame into
+    // that form): every rigid map the reference has is a RotateY and a Translate
+    // (hittable.rs:760-1001), so a box's second axis is the world's y, and the walls of a room are
+    // along all three.  Such an axis needs no dot products, its planes are world coordinates, and
+    // its crossing (plane - o) * rcp(d) is the quad test's own arithmetic for a face with a unit
+    // normal, bit for bit.  General frame ~70 vector instructions, upright ~50, world-aligned ~40.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    struct BoxAxis {
+        float t_lo, t_hi;
+        uint32_t r_in, r_out;
+    };
+    // The records come sorted by class (aligned, upright, general), one loop per class: a class
+    // word read per box would put a second scalar-load round trip into every iteration.
     const RT_CONST_AS float *B = as_uniform(sc.flat_boxes);
-    for (uint32_t k = 0; k < sc.n_flat_boxes; ++k, B += 32) {
-        const V3 oc = {o.x - B[9], o.y - B[10], o.z - B[11]};
-        float t_lo[3], t_hi[3];
-        uint32_t r_in[3], r_out[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const V3 e = {B[3 * a], B[3 * a + 1], B[3 * a + 2]};
-            const float od = dot(e, oc), dd = dot(e, d), inv = __builtin_amdgcn_rcpf(dd);
-            const float ta = (B[12 + a] - od) * inv, tb = (B[15 + a] - od) * inv;
-            t_lo[a] = fminf(ta, tb), t_hi[a] = fmaxf(ta, tb);
+    const uint32_t n_boxes = sc.n_flat_boxes, n_aligned = sc.n_flat_boxes_aligned, n_upright = sc.n_flat_boxes_upright;
+    asm volatile("" ::"s"(B), "s"(n_boxes), "s"(n_aligned), "s"(n_upright)); // one request, one wait
+    if (n_boxes) {
+        // planes: (lo, hi) along the axis, od: the origin there, dd: the direction there
+        auto axis = [&](int a, float od, float dd, float inv) {
+            const v2f planes = {B[12 + 2 * a], B[13 + 2 * a]};
+            const v2f t2 = (planes - v2f{od, od}) * v2f{inv, inv};
+            BoxAxis r;
+            r.t_lo = fminf(t2.x, t2.y), r.t_hi = fmaxf(t2.x, t2.y);
             const bool up = dd > 0.0f; // enters through the lo face, leaves through the hi face
             const uint32_t rl = fbits(B[18 + a]), rh = fbits(B[21 + a]);
-            r_in[a] = up ? rl : rh, r_out[a] = up ? rh : rl;
+            r.r_in = up ? rl : rh, r.r_out = up ? rh : rl;
+            return r;
+        };
+        auto closest = [&](const BoxAxis &x, const BoxAxis &y, const BoxAxis &z) {
+            const float t_near = fmaxf(fmaxf(x.t_lo, y.t_lo), z.t_lo), t_far = fminf(fminf(x.t_hi, y.t_hi), z.t_hi);
+            const uint32_t near_ref = x.t_lo >= fmaxf(y.t_lo, z.t_lo) ? x.r_in : (y.t_lo >= z.t_lo ? y.r_in : z.r_in);
+            const uint32_t far_ref = x.t_hi <= fminf(y.t_hi, z.t_hi) ? x.r_out : (y.t_hi <= z.t_hi ? y.r_out : z.r_out);
+            // (a face may be absent -- a room open on one side: RT_REF_NONE, never a hit)
+            const bool use_near = (t_near >= tlo) & (near_ref != origin_ref) & (near_ref != RT_REF_NONE);
+            const float tc = use_near ? t_near : t_far;
+            const uint32_t rcand = use_near ? near_ref : far_ref;
+            // A later quad wins a tie (t <= closest, hittable.rs:252-264), and ties happen: a box
+            // stands on the floor, its bottom face in the floor's plane.  The quad records give such
+            // a pair the same t to the bit; the slab arithmetic of a general frame differs from
+            // theirs in the last bits, so the tie is taken within 4 ulp.
+            const bool ok = (t_near <= t_far) & (tc >= tlo) & (tc <= best.t * (1.0f + 0x1p-21f)) & (rcand != origin_ref) & (rcand != RT_REF_NONE);
+            best.t = ok ? tc : best.t;
+            best.ref = ok ? rcand : best.ref;
+        };
+        const float inv_dy = __builtin_amdgcn_rcpf(d.y);
+        uint32_t k = 0;
+        if (n_aligned) {
+            const float inv_dx = __builtin_amdgcn_rcpf(d.x), inv_dz = __builtin_amdgcn_rcpf(d.z);
+            for (; k < n_aligned; ++k, B += 32) closest(axis(0, o.x, d.x, inv_dx), axis(1, o.y, d.y, inv_dy), axis(2, o.z, d.z, inv_dz));
         }
-        const float t_near = fmaxf(fmaxf(t_lo[0], t_lo[1]), t_lo[2]), t_far = fminf(fminf(t_hi[0], t_hi[1]), t_hi[2]);
-        const uint32_t near_ref = t_lo[0] >= fmaxf(t_lo[1], t_lo[2]) ? r_in[0] : (t_lo[1] >= t_lo[2] ? r_in[1] : r_in[2]);
-        const uint32_t far_ref = t_hi[0] <= fminf(t_hi[1], t_hi[2]) ? r_out[0] : (t_hi[1] <= t_hi[2] ? r_out[1] : r_out[2]);
-        // (a face may be absent -- a room open on one side: RT_REF_NONE, never a hit)
-        const bool use_near = (t_near >= tlo) & (near_ref != origin_ref) & (near_ref != RT_REF_NONE);
-        const float tc = use_near ? t_near : t_far;
-        const uint32_t rcand = use_near ? near_ref : far_ref;
-        // A later quad wins a tie (t <= closest, hittable.rs:252-264), and ties happen: a box
-        // stands on the floor, its bottom face in the floor's plane.  The quad records give such
-        // a pair the same t to the bit; the slab arithmetic differs from theirs in the last
-        // bits, so the tie is taken within 4 ulp.
-        const bool ok = (t_near <= t_far) & (tc >= tlo) & (tc <= best.t * (1.0f + 0x1p-21f)) & (rcand != origin_ref) & (rcand != RT_REF_NONE);
-        best.t = ok ? tc : best.t;
-        best.ref = ok ? rcand : best.ref;
+        for (const uint32_t end = k + n_upright; k < end; ++k, B += 32) {
+            // e0 and e2 lie in the xz plane; their planes are measured from the centre
+            const float ocx = o.x - B[9], ocz = o.z - B[11];
+            const float od0 = fmaf(B[0], ocx, B[2] * ocz), dd0 = fmaf(B[0], d.x, B[2] * d.z);
+            const float od2 = fmaf(B[6], ocx, B[8] * ocz), dd2 = fmaf(B[6], d.x, B[8] * d.z);
+            closest(axis(0, od0, dd0, __builtin_amdgcn_rcpf(dd0)), axis(1, o.y, d.y, inv_dy), axis(2, od2, dd2, __builtin_amdgcn_rcpf(dd2)));
+        }
+        for (; k < n_boxes; ++k, B += 32) {
+            const V3 oc = {o.x - B[9], o.y - B[10], o.z - B[11]};
+            float od[3], dd[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const V3 e = {B[3 * a], B[3 * a + 1], B[3 * a + 2]};
+                od[a] = dot(e, oc), dd[a] = dot(e, d);
+            }
+            closest(axis(0, od[0], dd[0], __builtin_amdgcn_rcpf(dd[0])), axis(1, od[1], dd[1], __builtin_amdgcn_rcpf(dd[1])),
+                    axis(2, od[2], dd[2], __builtin_amdgcn_rcpf(dd[2])));
+        }
     }
     const RT_CONST_AS uint32_t *other = as_uniform(sc.flat_other);
     for (uint32_t k = 0; k < sc.n_flat_other; ++k) test_prim<true>(sc, other[k], o, d, time, tlo, origin_ref, rc, best);

@@ -498,6 +498,8 @@ def test_cornell_walls_are_recognised_as_a_room(device):
         scene(name, device)
         info = device.accel_info()
         assert info["kind"] == "flat" and info["flat_boxes"] == boxes and info["flat_quads"] == 1, info  # the lamp stays a quad
+        # the room's frame is the world's; the inner boxes stand under RotateY + Translate
+        assert info["flat_boxes_aligned"] == 1 and info["flat_boxes_upright"] == boxes - 1, info
     # through the open side from outside, out through it from inside, and onto the outside of a wall
     o = np.float32([[278, 278, -800], [400, 450, 100], [-100, 278, 278], [278, 278, 300], [278, 900, 278]])
     d = np.float32([[0, 0, 1], [0.2, 0.1, -1], [1, 0, 0], [0, -1, 0.2], [0, -1, 0]])
@@ -532,8 +534,10 @@ def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device
     behind them (every face tested as a quad) give the same primitive and t for rays from
     outside, from inside a box, off a face (origin_prim set) and grazing, and both agree with the
     oracle.  A box standing on the floor shares its bottom plane with it: the later primitive
-    wins the tie, as in HittableVec::hit."""
-    def build(sb, boxes_last):
+    wins the tie, as in HittableVec::hit.  The slab test has a form per kind of frame (along the
+    world axes, upright, general) and runs them in that order: a list that orders its boxes that
+    way gets the short forms, any other list the general form for all; both are run here."""
+    def build(sb, boxes_last, aligned_first=False):
         white = sb.lambertian(sb.tex_solid(0.7, 0.7, 0.7))
         floor = sb.quad((-6, 0, -6), (12, 0, 0), (0, 0, 12), white)
         wall = sb.quad((-6, 0, -6), (12, 0, 0), (0, 8, 0), white)
@@ -541,13 +545,14 @@ def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device
         b1 = sb.translate(sb.rotate_y(sb.box3((0, 0, 0), (2, 3, 2), white), 20.0), (-3.5, 0, -1))
         b2 = sb.translate(sb.rotate_y(sb.box3((0, 0, 0), (1.5, 1.5, 1.5), white), -33.0), (1.5, 0, 0.5))
         b3 = sb.box3((-0.5, 2.0, -4.0), (0.5, 2.5, -3.0), white)  # axis-aligned, off the floor
-        objs = [floor, wall, b1, b2, b3, lamp] if not boxes_last else [floor, wall, lamp, b1, b2, b3]
+        boxes = [b3, b1, b2] if aligned_first else [b1, b2, b3]
+        objs = [floor, wall] + boxes + [lamp] if not boxes_last else [floor, wall, lamp] + boxes
         sb.set_world(sb.list(objs))
         sb.set_lights(lamp)
     hosts = {}
-    for boxes_last in (True, False):
+    for boxes_last in (True, False, "by class"):
         host, osb = ra.SceneBuilder(), orc.scene()
-        build(host, boxes_last), build(osb, boxes_last)
+        build(host, bool(boxes_last), boxes_last == "by class"), build(osb, bool(boxes_last), boxes_last == "by class")
         hosts[boxes_last] = (host, osb)
     cam = ra.CameraSettings(image_width=64, image_height=64, samples_per_px=16, max_depth=8, vfov=60.0, background=(0.0, 0.0, 0.0),
                             camera_center=(0.5, 4.0, 9.0), camera_target=(0.0, 1.5, 0.0))
@@ -557,6 +562,7 @@ def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device
         info = device.accel_info()
         assert info["kind"] == "flat" and info["flat_boxes"] == (3 if boxes_last else 0)
         assert info["flat_quads"] == (3 if boxes_last else 21)
+        assert (info["flat_boxes_aligned"], info["flat_boxes_upright"]) == ((1, 2) if boxes_last == "by class" else (0, 0))
         o, d, tm, frm = helpers.ray_batch(osb, cam, 32768, seed=5, bbox=((-6, 0, -6), (6, 8, 6)))
         # rays born inside the first two boxes and on the floor under them
         rng = np.random.default_rng(2)
@@ -579,21 +585,24 @@ def test_boxes_of_a_flat_world_are_tested_as_boxes_with_the_quads_answers(device
         want = orc.intersect_batch(osb, down_o, np.tile(np.float32([0, -1, 0]), (2, 1)), np.zeros(2))
         assert (down[1] == want[1]).all() and (down[0] == 1).all()
         res[boxes_last] = (o, hit, prim, t)
-    (o1, h1, p1, t1), (o0, h0, p0, t0) = res[True], res[False]
-    # the two list orders number the primitives differently; compare hit flags and distances
-    assert np.array_equal(o1, o0) and (h1 == h0).mean() > 0.999
-    both = (h1 == 1) & (h0 == 1)
-    assert np.quantile(np.abs(t1[both] - t0[both]) / t0[both], 0.999) < 1e-5
-    # and a render through the box path against the oracle, same stream
-    host, osb = hosts[True]
-    device.upload(host)
+    (o0, h0, p0, t0) = res[False]
+    for order in (True, "by class"):
+        (o1, h1, p1, t1) = res[order]
+        # the list orders number the primitives differently; compare hit flags and distances
+        assert np.array_equal(o1, o0) and (h1 == h0).mean() > 0.999
+        both = (h1 == 1) & (h0 == 1)
+        assert np.quantile(np.abs(t1[both] - t0[both]) / t0[both], 0.999) < 1e-5
+    # and renders through the box path against the oracle, same stream
     device.film_resize(64, 64)
-    for pipeline in ("lane-bound", "regrouped"):
-        device.film_clear()
-        device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=9, **PIPELINES[pipeline])
+    for order in (True, "by class"):
+        host, osb = hosts[order]
+        device.upload(host)
         film, _, _ = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=9)
-        r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
-        assert r["median_rel"] < 1.2e-7 and r["frac_5e2"] < FORKED, (pipeline, r)
+        for pipeline in ("lane-bound", "regrouped"):
+            device.film_clear()
+            device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=9, **PIPELINES[pipeline])
+            r = helpers.compare_same_stream(device.film(1.0 / 16), film / 16)
+            assert r["median_rel"] < 1.2e-7 and r["frac_5e2"] < FORKED, (order, pipeline, r)
 
 
 @pytest.mark.parametrize("pipeline", list(PIPELINES))
