@@ -20,7 +20,7 @@ MAIN = bin/rt_main
 
 all: $(LIB) $(MAIN) oracle sanitize
 
-$(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h raytracing_amd/csrc/rt_leafword.h include/rt_amd.h
+$(DEV_OBJ): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h raytracing_amd/csrc/rt_leafword.h raytracing_amd/csrc/rt_flat.h include/rt_amd.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 raytracing_amd/host/%.o: raytracing_amd/host/%.cpp raytracing_amd/host/raytracing.hpp include/rt_amd.h
@@ -37,7 +37,7 @@ $(MAIN): raytracing_amd/host/main.o $(LIB)
 SAN_SRC = raytracing_amd/host/scene.cpp raytracing_amd/host/flatten.cpp raytracing_amd/host/config.cpp \
           raytracing_amd/host/image_io.cpp raytracing_amd/host/host_capi.cpp tests/native/host_sanitize.cpp
 sanitize: bin/host_sanitize
-bin/host_sanitize: $(SAN_SRC) raytracing_amd/host/raytracing.hpp raytracing_amd/csrc/rt_accel.h include/rt_amd.h
+bin/host_sanitize: $(SAN_SRC) raytracing_amd/host/raytracing.hpp raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_flat.h include/rt_amd.h
 	mkdir -p bin
 	g++ -O1 -g $(CXXSTD) -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer \
 	    -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -o $@ $(SAN_SRC) -lz
@@ -45,7 +45,7 @@ bin/host_sanitize: $(SAN_SRC) raytracing_amd/host/raytracing.hpp raytracing_amd/
 # the same library with per-step counters in the regrouping kernel (tools/regroup_steps.py)
 STATS_LIB = raytracing_amd/librt_amd_stats.so
 stats-lib: $(STATS_LIB)
-$(STATS_LIB): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h raytracing_amd/csrc/rt_leafword.h include/rt_amd.h $(HOST_OBJ)
+$(STATS_LIB): raytracing_amd/csrc/rt_device.hip raytracing_amd/csrc/rt_kernels.h raytracing_amd/csrc/rt_accel.h raytracing_amd/csrc/rt_math.h raytracing_amd/csrc/rt_leafword.h raytracing_amd/csrc/rt_flat.h include/rt_amd.h $(HOST_OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRT_REGROUP_STATS -c $< -o raytracing_amd/csrc/rt_device_stats.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ raytracing_amd/csrc/rt_device_stats.o $(HOST_OBJ) -lz
 

@@ -260,7 +260,9 @@ typedef struct {
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 /* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it
  * against the descriptor -- same leaves, boxes that contain their content, forward indices.
- * stack_entries reports the exact stack need.  Returns 0, or < 0 with the reason in err. */
+ * stack_entries reports the exact stack need; the flat_* fields say what the upload would make
+ * of the scene as a flat world (all 0 unless the world is one list of primitives).  Returns 0,
+ * or < 0 with the reason in err. */
 int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_info *out, char *err, uint32_t err_len);
 
 /* The pixel x stratum loop of camera.rs:386-401 for strata [begin,end): every sample's

@@ -77,9 +77,6 @@ struct DScene {
     uint32_t stack4, lds_nodes4;
 };
 
-// how much of a flat world's box frame is the world's own (the class word of a box record, scan_flat)
-enum : uint32_t { RT_BOX_GENERAL = 0, RT_BOX_UPRIGHT = 1, RT_BOX_ALIGNED = 2 };
-
 // which structure a kernel instance searches
 // ACCEL_BVH4Q: the 4-wide tree with 64-byte nodes whose child boxes are 8-bit offsets on a grid of
 // the node's own (see trav4_round); ACCEL_BVH4: the same tree with 128-byte fp32 nodes.

@@ -7,11 +7,13 @@
 //   3. PNG writer -> reader round trip and the reader on damaged files;
 //   4. camera builder on hostile numbers.
 #include "../../raytracing_amd/csrc/rt_accel.h"
+#include "../../raytracing_amd/csrc/rt_flat.h"
 #include "../../raytracing_amd/host/raytracing.hpp"
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -63,6 +65,26 @@ bool load_and_build(const std::string &text, const std::string &base, bool scene
         if (rth_flatten(s, &desc) == 0 && desc) {
             ok = true;
             if (n_prims) *n_prims = size_t(desc->n_quads) + desc->n_spheres + desc->n_media;
+            {
+                // the flat scan's records: whatever the list holds, the plan accounts for every quad once
+                flat::Plan fp;
+                const std::string err = flat::plan(desc, fp);
+                if (verify) check(err.empty(), "flat::plan: " + err);
+                if (err.empty() && fp.flat) {
+                    size_t quads_in_boxes = 0;
+                    for (size_t b = 0; b < fp.boxes.size() / 32; ++b)
+                        for (int f = 18; f < 24; ++f) {
+                            uint32_t ref;
+                            std::memcpy(&ref, &fp.boxes[32 * b + f], 4);
+                            quads_in_boxes += ref != RT_REF_NONE;
+                        }
+                    size_t list_quads = 0;
+                    const rt_node &root = desc->nodes[desc->root & RT_REF_INDEX_MASK];
+                    for (uint32_t k = 0; k < root.count; ++k) list_quads += (desc->refs[root.left + k] >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD;
+                    check(fp.n_quads + quads_in_boxes == list_quads, "flat::plan: quads of the list not accounted for once");
+                    check(fp.n_boxes_aligned + fp.n_boxes_upright <= fp.boxes.size() / 32, "flat::plan: class counts");
+                }
+            }
             for (uint32_t builder : {uint32_t(RT_BUILD_REFERENCE), uint32_t(RT_BUILD_SAH)}) {
                 std::vector<rt::Node4> nodes;
                 uint32_t root = 0;

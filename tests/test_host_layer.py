@@ -535,6 +535,55 @@ def test_wide_bvh_is_a_regrouping_of_the_descriptor(name):
     desc.contents.root = saved
 
 
+def _flat_plan(sb):
+    """What the upload would make of the scene as a flat world, from the host-only self-test."""
+    err = C.create_string_buffer(512)
+    info = _ffi.RtAccelInfo()
+    assert lib.rt_accel_selftest(sb.flatten(), _ffi.RT_BUILD_AUTO, C.byref(info), err, 512) == 0, err.value
+    return dict(quads=info.flat_quads, boxes=info.flat_boxes, aligned=info.flat_boxes_aligned, upright=info.flat_boxes_upright,
+                alone=info.flat_alone_spheres)
+
+
+def test_flat_world_plan_recognises_rooms_and_boxes_without_a_gpu():
+    """The records of the flat scan are planned on the host: the five walls of cornell_box.toml are a
+    room along the world axes, box3 under RotateY + Translate is an upright box, the lamp stays a
+    quad; a list that orders its boxes against the class order keeps general frames; a quad in a
+    wall's plane later in the list keeps the walls quads (it would take ties from the wall); a BVH
+    world plans nothing."""
+    sb = ra.SceneBuilder()
+    ra.scenes.cornell_main(sb)
+    assert _flat_plan(sb) == dict(quads=1, boxes=3, aligned=1, upright=2, alone=0)
+    sb = ra.SceneBuilder()
+    ra.scenes.cornell_book3(sb)
+    assert _flat_plan(sb) == dict(quads=1, boxes=2, aligned=1, upright=1, alone=1)
+
+    def world(order, poster=False, tilt=None):
+        sb = ra.SceneBuilder()
+        white = sb.lambertian((0.7, 0.7, 0.7))
+        floor = sb.quad((-6, 0, -6), (12, 0, 0), (0, 0, 12), white)
+        lamp = sb.quad((-1, 7.9, -1), (2, 0, 0), (0, 0, 2), sb.light((9.0, 9.0, 9.0)))
+        upright = sb.translate(sb.rotate_y(sb.box3((0, 0, 0), (2, 3, 2), white), 20.0), (-3.5, 0, -1))
+        aligned = sb.box3((-0.5, 2.0, -4.0), (0.5, 2.5, -3.0), white)
+        objs = [floor, lamp] + [dict(u=upright, a=aligned)[c] for c in order]
+        sb.set_world(sb.list(objs))
+        sb.set_lights(lamp)
+        return sb
+    assert _flat_plan(world("au")) == dict(quads=2, boxes=2, aligned=1, upright=1, alone=0)
+    assert _flat_plan(world("ua")) == dict(quads=2, boxes=2, aligned=0, upright=0, alone=0)  # general frames, list order
+    assert _flat_plan(world("u")) == dict(quads=2, boxes=1, aligned=0, upright=1, alone=0)
+    # a poster on the back wall of the Cornell room
+    sb = ra.SceneBuilder()
+    objs = [sb.load_toml(ra.scenes.cornell_toml_text())]
+    poster = sb.quad((100.0, 100.0, 555.0), (200.0, 0.0, 0.0), (0.0, 200.0, 0.0), sb.lambertian((0.9, 0.1, 0.1)))
+    lamp = sb.quad((343.0, 554.0, 332.0), (-130.0, 0.0, 0.0), (0.0, 0.0, -105.0), sb.light((20.0, 20.0, 20.0)))
+    sb.set_world(sb.list(objs + [poster, lamp]))
+    sb.set_lights(lamp)
+    assert _flat_plan(sb) == dict(quads=7, boxes=0, aligned=0, upright=0, alone=0)
+    sb = ra.SceneBuilder()
+    ra.scenes.book1_final(sb, grid=3)
+    assert _flat_plan(sb) == dict(quads=0, boxes=0, aligned=0, upright=0, alone=0)
+
+
 def test_scene_file_camera_antialiasing_round_trip():
     from raytracing_amd import scene_toml
     rec = scene_toml.TomlRecorder()
