@@ -30,10 +30,10 @@ constexpr int WAVE = 64;
 constexpr int BLOCK = 256;          // 4 waves = 4 chunks per block
 constexpr int STACK_DEPTH = 32;     // per-lane traversal stack entries (LDS)
 constexpr int LDS_NODES = 128;      // BVH nodes staged per block (8 KiB)
-#ifndef RT_NODE_QUORUM
-#define RT_NODE_QUORUM 16
+#ifndef RT_NODE_SHARE
+#define RT_NODE_SHARE 2
 #endif
-constexpr uint32_t NODE_QUORUM = RT_NODE_QUORUM; // see trav4_round
+constexpr uint32_t NODE_SHARE = RT_NODE_SHARE; // see trav4_round
 #ifndef RT_SHADE_QUORUM
 #define RT_SHADE_QUORUM 48
 #endif
@@ -610,21 +610,27 @@ template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE =
 __device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
                                             const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best) {
     const RayConsts rcn = ray_consts(o, d);
-    // Node steps run while at least NODE_QUORUM lanes of the wave are at a node (or no lane
-    // holds a primitive); then the lanes that hold a primitive test it while the few node
-    // lanes wait.  Waiting for the last node lane instead (quorum 1) idles most of the wave.
+    // Node steps run while the lanes at a node outnumber the lanes that hold a primitive by
+    // NODE_SHARE to one; then the lanes that hold a primitive test it while the node lanes wait.
+    // Waiting for the last node lane instead idles most of the wave.  (A fixed quorum of 16 node
+    // lanes, the rule before this one, was 4 % slower on the Book-2 final scene and 6 % slower on
+    // the 1 M-primitive scene: what matters is how many lanes each kind of step would leave idle.)
     for (;;) {
         const bool at_node = (cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE;
         const uint32_t n_node = uint32_t(__popcll(__ballot(at_node)));
         if (n_node == 0) break;
-        if (n_node < NODE_QUORUM && __ballot(!at_node && cur != RT_REF_NONE) != 0) break;
+        if (n_node < NODE_SHARE * uint32_t(__popcll(__ballot(!at_node && cur != RT_REF_NONE)))) break;
         if (!at_node) continue;
         uint32_t key[4], ref[4];
         // Large trees (the ones that take byte boxes) are searched with all four children in
         // order of distance; on small trees, which live in LDS and whose cost is instructions, only
         // the nearest child is singled out (measured: +3 to +5 % on trees of hundreds of nodes,
         // -4 % at 466 k nodes, where every needless visit is a trip to memory).
+#ifdef RT_SORT_POLICY
+        constexpr bool SORT = RT_SORT_POLICY == 2 || (RT_SORT_POLICY == 1 && QUANT);
+#else
         constexpr bool SORT = QUANT;
+#endif
         wide_node_visit<STAGED, QUANT, SORT>(sc, mem.l_nodes, mem.lds_bytes, rcn, tlo, best.t, cur, key, ref);
         if constexpr (SORT) {
             if (key[3] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[3]);
