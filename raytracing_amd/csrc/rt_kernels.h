@@ -606,70 +606,80 @@ key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                           
     }
 }
 
-template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK>
-__device__ __forceinline__ void trav4_round(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
-                                            const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best) {
+// Rounds for the lanes that call it together, until `more(lanes still traversing, lanes finished)`
+// says no (asked after every round, wave-uniform; both counts are of the calling lanes).  The
+// per-ray constants are made once per call: a caller that came back for every round paid for them
+// -- three reciprocals and the plane offsets -- once per primitive test.  Returns the rounds run.
+template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK, typename More>
+__device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
+                                                 const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best,
+                                                 More more) {
     const RayConsts rcn = ray_consts(o, d);
-    // Node steps run while the lanes at a node outnumber the lanes that hold a primitive by
-    // NODE_SHARE to one; then the lanes that hold a primitive test it while the node lanes wait.
-    // Waiting for the last node lane instead idles most of the wave.  (A fixed quorum of 16 node
-    // lanes, the rule before this one, was 4 % slower on the Book-2 final scene and 6 % slower on
-    // the 1 M-primitive scene: what matters is how many lanes each kind of step would leave idle.)
-    for (;;) {
-        const bool at_node = (cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE;
-        const uint32_t n_node = uint32_t(__popcll(__ballot(at_node)));
-        if (n_node == 0) break;
-        if (n_node < NODE_SHARE * uint32_t(__popcll(__ballot(!at_node && cur != RT_REF_NONE)))) break;
-        if (!at_node) continue;
-        uint32_t key[4], ref[4];
-        // Large trees (the ones that take byte boxes) are searched with all four children in
-        // order of distance; on small trees, which live in LDS and whose cost is instructions, only
-        // the nearest child is singled out (measured: +3 to +5 % on trees of hundreds of nodes,
-        // -4 % at 466 k nodes, where every needless visit is a trip to memory).
-#ifdef RT_SORT_POLICY
-        constexpr bool SORT = RT_SORT_POLICY == 2 || (RT_SORT_POLICY == 1 && QUANT);
-#else
-        constexpr bool SORT = QUANT;
-#endif
-        wide_node_visit<STAGED, QUANT, SORT>(sc, mem.l_nodes, mem.lds_bytes, rcn, tlo, best.t, cur, key, ref);
-        if constexpr (SORT) {
-            if (key[3] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[3]);
-            if (key[2] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[2]);
-            if (key[1] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[1]);
-            if (key[0] != 0xFFFFFFFFu) {
-                cur = ref[0];
-            } else if (sp) {
-                cur = trav_pop<SPILL, STRIDE>(mem, sp);
+    uint32_t rounds = 0;
+    do {
+        ++rounds;
+        // Node steps run while the lanes at a node outnumber the lanes that hold a primitive by
+        // NODE_SHARE to one; then the lanes that hold a primitive test it while the node lanes wait.
+        // Waiting for the last node lane instead idles most of the wave.  (A fixed quorum of 16 node
+        // lanes, the rule before this one, was 4 % slower on the Book-2 final scene and 6 % slower on
+        // the 1 M-primitive scene: what matters is how many lanes each kind of step would leave idle.)
+        for (;;) {
+            const bool at_node = (cur >> RT_REF_KIND_SHIFT) == RT_KIND_NODE;
+            const uint32_t n_node = uint32_t(__popcll(__ballot(at_node)));
+            if (n_node == 0) break;
+            if (n_node < NODE_SHARE * uint32_t(__popcll(__ballot(!at_node && cur != RT_REF_NONE)))) break;
+            if (!at_node) continue;
+            uint32_t key[4], ref[4];
+            // Large trees (the ones that take byte boxes) are searched with all four children in
+            // order of distance; on small trees, which live in LDS and whose cost is instructions, only
+            // the nearest child is singled out (measured: +3 to +5 % on trees of hundreds of nodes,
+            // -4 % at 466 k nodes, where every needless visit is a trip to memory).
+    #ifdef RT_SORT_POLICY
+            constexpr bool SORT = RT_SORT_POLICY == 2 || (RT_SORT_POLICY == 1 && QUANT);
+    #else
+            constexpr bool SORT = QUANT;
+    #endif
+            wide_node_visit<STAGED, QUANT, SORT>(sc, mem.l_nodes, mem.lds_bytes, rcn, tlo, best.t, cur, key, ref);
+            if constexpr (SORT) {
+                if (key[3] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[3]);
+                if (key[2] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[2]);
+                if (key[1] != 0xFFFFFFFFu) trav_push<SPILL, STRIDE>(mem, sp, ref[1]);
+                if (key[0] != 0xFFFFFFFFu) {
+                    cur = ref[0];
+                } else if (sp) {
+                    cur = trav_pop<SPILL, STRIDE>(mem, sp);
+                } else {
+                    cur = RT_REF_NONE;
+                }
             } else {
-                cur = RT_REF_NONE;
-            }
-        } else {
-            // The nearest child is visited next, the other children that are met go on the stack as
-            // they stand in the node: a full sort of the four costs a quarter of a visit's
-            // instructions, and the order of the far children only decides how soon they are culled.
-            const uint32_t nearest = min(min(key[0], key[1]), min(key[2], key[3]));
-            const bool n0 = key[0] == nearest, n1 = !n0 & (key[1] == nearest), n2 = !(n0 | n1) & (key[2] == nearest);
-            const bool n3 = !(n0 | n1 | n2);
-            if ((key[3] != 0xFFFFFFFFu) & !n3) trav_push<SPILL, STRIDE>(mem, sp, ref[3]);
-            if ((key[2] != 0xFFFFFFFFu) & !n2) trav_push<SPILL, STRIDE>(mem, sp, ref[2]);
-            if ((key[1] != 0xFFFFFFFFu) & !n1) trav_push<SPILL, STRIDE>(mem, sp, ref[1]);
-            if ((key[0] != 0xFFFFFFFFu) & !n0) trav_push<SPILL, STRIDE>(mem, sp, ref[0]);
-            if (nearest != 0xFFFFFFFFu) {
-                cur = n0 ? ref[0] : (n1 ? ref[1] : (n2 ? ref[2] : ref[3]));
-            } else if (sp) {
-                cur = trav_pop<SPILL, STRIDE>(mem, sp);
-            } else {
-                cur = RT_REF_NONE;
+                // The nearest child is visited next, the other children that are met go on the stack as
+                // they stand in the node: a full sort of the four costs a quarter of a visit's
+                // instructions, and the order of the far children only decides how soon they are culled.
+                const uint32_t nearest = min(min(key[0], key[1]), min(key[2], key[3]));
+                const bool n0 = key[0] == nearest, n1 = !n0 & (key[1] == nearest), n2 = !(n0 | n1) & (key[2] == nearest);
+                const bool n3 = !(n0 | n1 | n2);
+                if ((key[3] != 0xFFFFFFFFu) & !n3) trav_push<SPILL, STRIDE>(mem, sp, ref[3]);
+                if ((key[2] != 0xFFFFFFFFu) & !n2) trav_push<SPILL, STRIDE>(mem, sp, ref[2]);
+                if ((key[1] != 0xFFFFFFFFu) & !n1) trav_push<SPILL, STRIDE>(mem, sp, ref[1]);
+                if ((key[0] != 0xFFFFFFFFu) & !n0) trav_push<SPILL, STRIDE>(mem, sp, ref[0]);
+                if (nearest != 0xFFFFFFFFu) {
+                    cur = n0 ? ref[0] : (n1 ? ref[1] : (n2 ? ref[2] : ref[3]));
+                } else if (sp) {
+                    cur = trav_pop<SPILL, STRIDE>(mem, sp);
+                } else {
+                    cur = RT_REF_NONE;
+                }
             }
         }
-    }
-    if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
-        // a leaf's word carries the class of its material above the index (rt_accel.h)
-        const uint32_t before = best.ref;
-        test_prim(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best);
-        if (best.ref != before) best.cls = (cur & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
-        cur = sp ? trav_pop<SPILL, STRIDE>(mem, sp) : RT_REF_NONE;
-    }
+        if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
+            // a leaf's word carries the class of its material above the index (rt_accel.h)
+            const uint32_t before = best.ref;
+            test_prim(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best);
+            if (best.ref != before) best.cls = (cur & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
+            cur = sp ? trav_pop<SPILL, STRIDE>(mem, sp) : RT_REF_NONE;
+        }
+    } while (more(uint32_t(__popcll(__ballot(cur != RT_REF_NONE))), uint32_t(__popcll(__ballot(cur == RT_REF_NONE)))));
+    return rounds;
 }
 
 template <bool STAGED, bool QUANT>
@@ -678,8 +688,8 @@ __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, f
     uint32_t cur, sp;
     trav4_begin(thi, cur, sp, best);
     const TravMem mem = block_trav_mem(sc, s_dyn, QUANT ? 64u : 128u);
-    while (__ballot(cur != RT_REF_NONE) != 0) // until every lane of the wave is done
-        trav4_round<STAGED, QUANT>(sc, o, d, time, tlo, origin_ref, rc, mem, cur, sp, best);
+    // until every lane of the wave is done
+    trav4_rounds<STAGED, QUANT>(sc, o, d, time, tlo, origin_ref, rc, mem, cur, sp, best, [](uint32_t n_trav, uint32_t) { return n_trav != 0; });
 }
 
 // One entry for the three structures.  s_stack / s_nodes: static LDS of the binary traversal;
@@ -1530,10 +1540,12 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                 if (busy) {
                     RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
                     const TravMem mem = block_trav_mem(sc, s_dyn, ACCEL == ACCEL_BVH4Q ? 64u : 128u);
+                    // rounds until the lanes that finish bring the shading steps their quorum
+                    auto more = [&](uint32_t n_trav, uint32_t n_fin) { return n_trav != 0 && n_work + n_fin < SHADE_QUORUM; };
                     if (sc.lds_nodes4) // uniform
-                        trav4_round<true, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+                        trav4_rounds<true, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
                     else
-                        trav4_round<false, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+                        trav4_rounds<false, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
                 }
                 continue;
             }
@@ -2051,12 +2063,18 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
                                (!exhausted && n_free != 0 && n_trav < POOL_STARVE && n_ray == 0);
         if (n_trav != 0 && n_done < POOL_HARVEST && !can_refill && !can_shade) {
             // 1. a traversal round for the lanes that hold a ray
+            uint32_t rounds = 0;
             if (traversing) {
+                // one round per call: running them here until the pool has something else to do keeps 16 more
+                // scalar registers live through the rounds, and what the kernel then spills to vector lanes
+                // costs more than the per-ray constants made again for every round (measured: -12 %)
+                auto more = [](uint32_t, uint32_t) { return false; };
                 if (lds_nodes) // uniform
-                    trav4_round<true, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+                    rounds = trav4_rounds<true, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
                 else
-                    trav4_round<false, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best);
+                    rounds = trav4_rounds<false, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
             }
+            (void)rounds;
             RT_RG_COUNT(RG_RAY, n_trav);
             RT_POOL_TICK(RG_RAY);
             continue;
