@@ -51,6 +51,7 @@ struct rt_handle {
     accel::Stats accel_stats{};
     uint32_t has_media = 0, n_prims = 0, alone_spheres = 0, n_quads = 0, n_spheres = 0, n_materials = 0;
     bool has_specular = false;
+    bool has_motion = false; // some sphere moves: a ray's time matters
     uint32_t n_textures = 0;
     std::vector<uint32_t> prim_to_ref; // user-visible primitive id -> ref (parity hook)
 
@@ -291,7 +292,7 @@ uint32_t binary_stack_need(const rt_scene_desc *s) {
     return of(s->root);
 }
 
-int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCamera *out, uint32_t *se) {
+int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCamera *out, uint32_t *se, bool timeless = false) {
     if (!c || !p) return fail(h, "null camera or params");
     if (c->image_width < 1 || c->image_height < 1) return fail(h, "camera: empty image");
     if (uint64_t(c->image_width) * c->image_height > (1ull << 28)) return fail(h, "camera: image too large");
@@ -322,6 +323,7 @@ int make_camera(rt_handle *h, const rt_camera *c, const rt_render_params *p, DCa
     d.defocus = !(c->defocus_angle <= 0.0); // camera.rs:422
     d.sky = c->background_sky != 0;
     d.aa_disc = c->antialiasing == RT_AA_DISC;
+    d.timeless = timeless ? 1u : 0u; // the time of a ray is not drawn (camera_ray)
     *out = d;
     *se = e;
     // the kernels read the camera from device memory
@@ -802,6 +804,9 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     h->n_prims = s->n_prims;
     h->n_textures = s->n_textures;
     h->has_specular = false;
+    h->has_motion = false;
+    for (uint32_t i = 0; i < s->n_spheres; ++i)
+        if (s->spheres[i].moving || s->spheres[i].cv[0] != 0.f || s->spheres[i].cv[1] != 0.f || s->spheres[i].cv[2] != 0.f) h->has_motion = true;
     for (uint32_t i = 0; i < s->n_materials; ++i)
         if (s->materials[i].type == RT_MAT_METAL || s->materials[i].type == RT_MAT_DIELECTRIC) h->has_specular = true;
     h->prim_to_ref.assign(s->n_prims, RT_REF_NONE);
@@ -1013,7 +1018,9 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     if (!h->have_scene) return fail(h, "rt_render: no scene uploaded");
     DCamera dc;
     uint32_t stratum_end;
-    if (make_camera(h, cam, p, &dc, &stratum_end)) return -1;
+    // Nothing moves: the time of a ray (camera.rs:429, the camera stream's last draw) decides nothing
+    // and is not drawn -- behind a defocus disk that draw is a Philox block of its own.
+    if (make_camera(h, cam, p, &dc, &stratum_end, !h->has_motion)) return -1;
     if (p->mode > RT_MODE_BOOK3) return fail(h, "rt_render: unknown estimator mode");
     if (p->mode == RT_MODE_REF_EXACT) {
         // Mirrors the reference's panics: Metal/Dielectric scatter is todo!() (material.rs:128,179)

@@ -48,6 +48,17 @@ template <typename T> __device__ __forceinline__ const RT_CONST_AS T *as_uniform
     return reinterpret_cast<const RT_CONST_AS T *>(reinterpret_cast<uintptr_t>(p));
 }
 
+// instrumented builds (make stats-lib): turns, lanes and clock ticks per step of the persistent kernels
+constexpr uint32_t RG_STATS = 8;
+#ifdef RT_REGROUP_STATS
+__device__ unsigned long long g_rg_stats[3 * RG_STATS];
+struct TravStats { // of the wide traversal, per wave
+    unsigned long long node_steps = 0, node_lanes = 0, prim_steps = 0, prim_lanes = 0;
+};
+#else
+struct TravStats {};
+#endif
+
 struct DScene {
     const rt_node *nodes;
     const uint32_t *refs;
@@ -85,7 +96,7 @@ constexpr bool accel_is_wide(int accel) { return accel == ACCEL_BVH4 || accel ==
 
 struct DCamera {
     V3 p00_rel, du, dv, center, disk_u, disk_v, bg;
-    uint32_t W, H, npix, sqrt_spp, stratum_begin, max_depth, defocus, sky, aa_disc;
+    uint32_t W, H, npix, sqrt_spp, stratum_begin, max_depth, defocus, sky, aa_disc, timeless;
     float inv_sqrt, inv_w;
 };
 
@@ -613,7 +624,7 @@ key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                           
 template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK, typename More>
 __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
                                                  const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best,
-                                                 More more) {
+                                                 More more, TravStats *ts = nullptr) {
     const RayConsts rcn = ray_consts(o, d);
     uint32_t rounds = 0;
     do {
@@ -628,6 +639,9 @@ __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float 
             const uint32_t n_node = uint32_t(__popcll(__ballot(at_node)));
             if (n_node == 0) break;
             if (n_node < NODE_SHARE * uint32_t(__popcll(__ballot(!at_node && cur != RT_REF_NONE)))) break;
+#ifdef RT_REGROUP_STATS
+            if (ts) ts->node_steps += 1, ts->node_lanes += n_node;
+#endif
             if (!at_node) continue;
             uint32_t key[4], ref[4];
             // Large trees (the ones that take byte boxes) are searched with all four children in
@@ -671,6 +685,12 @@ __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float 
                 }
             }
         }
+#ifdef RT_REGROUP_STATS
+        if (ts) {
+            const uint32_t n_prim = uint32_t(__popcll(__ballot(cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE)));
+            ts->prim_steps += n_prim != 0, ts->prim_lanes += n_prim;
+        }
+#endif
         if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
             // a leaf's word carries the class of its material above the index (rt_accel.h)
             const uint32_t before = best.ref;
@@ -1098,7 +1118,7 @@ __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t 
         o = ldv(cam.center) + off;
         d = rel - off;
     }
-    time = rng.next();
+    time = cam.timeless ? 0.0f : rng.next(); // timeless: a render of a scene in which nothing moves
 }
 __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t stratum, uint32_t k0,
                                            uint32_t k1, V3 &o, V3 &d, float &time) {
@@ -1526,6 +1546,17 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     uint32_t cur = RT_REF_NONE, sp = 0; // cur != RT_REF_NONE: this lane is inside a traversal
     Best best;
     best.t = RT_INF, best.ref = RT_REF_NONE, best.u = best.v = 0.f;
+#ifdef RT_REGROUP_STATS
+    // wide BVH, per wave: 0 node steps, 1 primitive steps, 2 shading passes (lanes with a hit to look at),
+    // 3 lanes that scatter, 4 lanes that take a new sample, 5 calls for traversal rounds (lanes traversing)
+    TravStats ts;
+    unsigned long long pk_turns[RG_STATS] = {}, pk_lanes[RG_STATS] = {};
+#define RT_PK_COUNT(i, m) (pk_turns[i] += 1, pk_lanes[i] += (m))
+#define RT_PK_TS , &ts
+#else
+#define RT_PK_COUNT(i, m) ((void)0)
+#define RT_PK_TS
+#endif
     for (;;) {
         bool scatter = false; // the path goes on from a surface
         bool busy = false;    // (wide BVH) this lane is inside a traversal and skips the shading steps
@@ -1543,16 +1574,19 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                     // rounds until the lanes that finish bring the shading steps their quorum
                     auto more = [&](uint32_t n_trav, uint32_t n_fin) { return n_trav != 0 && n_work + n_fin < SHADE_QUORUM; };
                     if (sc.lds_nodes4) // uniform
-                        trav4_rounds<true, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
+                        trav4_rounds<true, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
                     else
-                        trav4_rounds<false, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
+                        trav4_rounds<false, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
                 }
+                RT_PK_COUNT(5, n_busy);
                 continue;
             }
             if (__ballot(alive) == 0 && exhausted) break;
+            RT_PK_COUNT(2, uint32_t(__popcll(__ballot(alive && !busy))));
             if (alive && !busy)
                 scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
                                      false, sf);
+            RT_PK_COUNT(3, uint32_t(__popcll(__ballot(scatter))));
         } else {
             // 1. closest hit, then what the hit itself contributes (background, emission)
             const unsigned long long live = __ballot(alive);
@@ -1607,6 +1641,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         //    shading stream of this vertex
         Rng rng;
         rng.begin(k0, k1, fbits(sa.w), sb.x, fresh ? STREAM_CAMERA : STREAM_SHADE, sb.y);
+        RT_PK_COUNT(4, uint32_t(__popcll(__ballot(fresh))));
         if (fresh) {
             V3 o, d;
             float time;
@@ -1629,7 +1664,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     if (lane == 0) {
         atomicAdd(&ctrl->segments, n_seg);
         atomicAdd(&ctrl->camera_rays, n_cam);
+#ifdef RT_REGROUP_STATS
+        pk_turns[0] = ts.node_steps, pk_lanes[0] = ts.node_lanes, pk_turns[1] = ts.prim_steps, pk_lanes[1] = ts.prim_lanes;
+        for (uint32_t i = 0; i < RG_STATS; ++i) atomicAdd(&g_rg_stats[i], pk_turns[i]), atomicAdd(&g_rg_stats[RG_STATS + i], pk_lanes[i]);
+#endif
     }
+#undef RT_PK_COUNT
+#undef RT_PK_TS
 }
 
 // ------------------------------------------------------------------ persistent path kernel, regrouping
@@ -1667,9 +1708,8 @@ static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE, "slot numbers are b
 #ifndef RT_REGROUP_WAVES
 #define RT_REGROUP_WAVES 4
 #endif
-constexpr uint32_t RG_STATS = RG_LISTS + 2; // instrumented builds: the lists' steps, then harvest and refill of k_paths_pool
+static_assert(RG_STATS == RG_LISTS + 2, "the lists' steps, then harvest and refill of k_paths_pool");
 #ifdef RT_REGROUP_STATS
-__device__ unsigned long long g_rg_stats[3 * RG_STATS]; // turns, lanes and clock ticks per step (instrumented builds)
 #define RT_RG_COUNT(stage, m) (rg_turns[stage] += 1, rg_lanes[stage] += (m))
 #else
 #define RT_RG_COUNT(stage, m) ((void)0)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Step statistics of the lane-bound persistent kernel behind the wide tree: how many node steps,
+primitive steps and shading passes a wave runs and with how many lanes each.  Needs the
+instrumented library (make stats-lib):
+
+    RT_AMD_LIBRARY=$PWD/raytracing_amd/librt_amd_stats.so python tools/lane_bound_steps.py [c2|c4|c5]
+"""
+import sys, ctypes as C
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: F401
+import raytracing_amd as ra
+from bench import WORKLOADS
+dev = ra.Device(0)
+for name in (sys.argv[1:] or ["c2", "c4"]):
+    fn, kw, mode, _ = WORKLOADS[name]
+    kw = dict(kw, spp={"c2": 36, "c4": 64, "c5": 4}[name])
+    sb = ra.SceneBuilder(); cam = fn(sb, **kw); dev.upload(sb)
+    dev.film_resize(cam.image_width, cam.image_height); rc = cam.build()
+    NL = 8
+    out = (C.c_ulonglong * (3 * NL))()
+    dev.lib.rt_debug_regroup_stats(out)
+    st = dev.render(rc, mode=mode, seed=2, regroup=False, time_kernels=True)
+    assert dev.lib.rt_debug_regroup_stats(out) == 0
+    names = ["node steps", "primitive steps", "shading passes (lanes with a hit)", "  lanes that scatter", "  lanes taking a sample", "calls for rounds (lanes traversing)"]
+    seg = st.segments
+    print(f"== {name}: {seg} segments, {st.kernel_ms[4]:.3f} ms")
+    for i, n in enumerate(names):
+        t, l = out[i], out[NL + i]
+        print(f"{n:38s} steps {t:12d}  lanes/step {l / max(t, 1):6.2f}  lane-steps per segment {l / seg:7.3f}  wave-steps per 64 segments {64 * t / seg:7.3f}")
