@@ -63,7 +63,7 @@ FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0, "c2": 1310.7, "c4": 1248.7, "c5":
 # WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments), keyed by
 # (workload, regrouping variant): profiles/r2_pmc_c3_spp64.txt and
 # profiles/r1g_pmc_c3_spp64_persistent.txt.  Not collected live: counters need their own runs.
-PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 498 + 4073518) * 1024 / 861.4e6,
+PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 552 + 4073822) * 1024 / 861.4e6,
                          ("c3", False): (2 * 12796 + 4905618) * 1024 / 861.4e6}
 
 
