@@ -256,6 +256,8 @@ typedef struct {
     uint32_t flat_boxes_upright; /* of flat_boxes: one axis the world's y, as under RotateY and Translate
                              * (hittable.rs:760-1001); the slab test skips the dot products such axes
                              * do not need.  Both are 0 when the list orders its boxes otherwise. */
+    uint32_t flat_rects;    /* flat only: rectangles along the world's axes (a lamp under a ceiling) that left
+                             * flat_quads for a test without dot products; same hits, same tie order */
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 /* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it

@@ -87,7 +87,7 @@ RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
 class RtAccelInfo(C.Structure):
     _fields_ = [("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32), ("cost", f64),
                 ("flat_quads", u32), ("flat_boxes", u32), ("flat_alone_spheres", u32), ("node_bytes", u32),
-                ("flat_boxes_aligned", u32), ("flat_boxes_upright", u32)]
+                ("flat_boxes_aligned", u32), ("flat_boxes_upright", u32), ("flat_rects", u32)]
 
 
 RT_BUILD_REFERENCE, RT_BUILD_SAH, RT_BUILD_AUTO = 0, 1, 2

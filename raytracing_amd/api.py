@@ -287,7 +287,7 @@ class Device:
         self._check(self.lib.rt_get_accel_info(self.h, C.byref(a)), "rt_get_accel_info")
         return dict(kind=("flat", "bvh2", "bvh4")[a.kind], nodes=a.nodes, depth=a.depth, stack_entries=a.stack_entries, cost=a.cost,
                     flat_quads=a.flat_quads, flat_boxes=a.flat_boxes, flat_alone_spheres=a.flat_alone_spheres, node_bytes=a.node_bytes,
-                    flat_boxes_aligned=a.flat_boxes_aligned, flat_boxes_upright=a.flat_boxes_upright)
+                    flat_boxes_aligned=a.flat_boxes_aligned, flat_boxes_upright=a.flat_boxes_upright, flat_rects=a.flat_rects)
 
     def upload(self, scene: SceneBuilder):
         desc = scene.flatten()

@@ -701,8 +701,12 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
             return rollback();
         }
     }
-    std::vector<float> &flat_quads = fp.quads, &flat_boxes = fp.boxes, &flat_pairs = fp.pairs;
+    std::vector<float> &flat_quads = fp.quads, &flat_pairs = fp.pairs;
     std::vector<uint32_t> &flat_other = fp.other;
+    // one array for the scan's second half: the rectangles' records, padded to whole box records, then the boxes'
+    std::vector<float> flat_boxes(fp.rects);
+    flat_boxes.resize((flat_boxes.size() + 31) / 32 * 32, 0.0f);
+    flat_boxes.insert(flat_boxes.end(), fp.boxes.begin(), fp.boxes.end());
     // device copy of the spheres: pad = 1 marks a sphere of a flat world that nothing reaches into
     std::vector<rt_sphere> spheres(s->spheres, s->spheres + s->n_spheres);
     for (rt_sphere &sp : spheres) sp.pad = 0;
@@ -765,7 +769,8 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.n_flat_pairs = uint32_t(flat_pairs.size() / 32);
     d.n_flat_quads = fp.n_quads; // (the array is padded with records that cannot hit)
     d.n_flat_other = uint32_t(flat_other.size());
-    d.n_flat_boxes = uint32_t(flat_boxes.size() / 32);
+    d.n_flat_boxes = uint32_t(fp.boxes.size() / 32);
+    d.n_flat_rects = uint32_t(fp.rects.size() / 8);
     d.n_flat_boxes_aligned = fp.n_boxes_aligned, d.n_flat_boxes_upright = fp.n_boxes_upright;
     if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, spheres.data(), spheres.size(), &ds) ||
@@ -857,6 +862,7 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
         if (!e.empty()) return say("rt_accel_selftest: " + e);
         out->flat_quads = fp.n_quads, out->flat_boxes = uint32_t(fp.boxes.size() / 32), out->flat_alone_spheres = uint32_t(fp.alone_spheres.size());
         out->flat_boxes_aligned = fp.n_boxes_aligned, out->flat_boxes_upright = fp.n_boxes_upright;
+        out->flat_rects = uint32_t(fp.rects.size() / 8);
         out->node_bytes = uint32_t(sizeof(Node4Q));
         std::vector<Node4Q> q;
         accel::quantise_nodes(nodes, q);
@@ -881,6 +887,7 @@ int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     out->flat_alone_spheres = h->alone_spheres;
     out->flat_boxes_aligned = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_aligned : 0u;
     out->flat_boxes_upright = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_upright : 0u;
+    out->flat_rects = h->accel == ACCEL_FLAT ? h->sc.n_flat_rects : 0u;
     return 0;
 }
 

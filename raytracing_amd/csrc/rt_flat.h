@@ -165,6 +165,38 @@ inline bool quad_in_a_face_plane(const rt_quad &other, const rt_quad *const *fac
     return false;
 }
 
+// A rectangle along the world's axes -- a lamp under a ceiling, a floor: the normal is exactly +-a
+// world axis and each edge runs exactly along one of the two others (tests on the fp32 record).  The
+// quad test (hittable.rs:341-371) then needs no dot products: t = (plane - o_n) * rcp(d_n), and
+// alpha, beta are one coordinate of the hit point each, scaled -- the same arithmetic the packed quad
+// test does with the zeros left out, bit for bit.  The inside rule 0 <= alpha, beta <= 1 does not tell
+// the two edges apart, so the in-plane axes are stored in ascending order.
+//   record, 8 floats: plane, Q_a, Q_b, 1/extent_a (signed), 1/extent_b (signed), ref, -, normal axis
+inline bool match_rect(const rt_quad &q, uint32_t ref, float rec[8]) {
+#ifdef RT_NO_RECTS // experiments: every such rectangle stays a quad
+    return false;
+#endif
+    if (q.shape != RT_SHAPE_PARALLELOGRAM) return false;
+    auto only = [](const float *v) { // the one axis v has a component along, or -1
+        int k = -1;
+        for (int a = 0; a < 3; ++a)
+            if (v[a] != 0.0f) k = k < 0 ? a : 3;
+        return k < 3 ? k : -1;
+    };
+    const int kn = only(q.n), ka = only(q.avec), kb = only(q.bvec);
+    if (kn < 0 || ka < 0 || kb < 0 || kn == ka || kn == kb || ka == kb) return false;
+    if (std::fabs(q.n[kn]) != 1.0f || !std::isfinite(q.avec[ka]) || !std::isfinite(q.bvec[kb])) return false;
+    const bool swap = ka > kb;
+    const int a = swap ? kb : ka, b = swap ? ka : kb;
+    rec[0] = q.q[kn], rec[1] = q.q[a], rec[2] = q.q[b];
+    rec[3] = swap ? q.bvec[kb] : q.avec[ka], rec[4] = swap ? q.avec[ka] : q.bvec[kb];
+    std::memcpy(&rec[5], &ref, 4);
+    rec[6] = 0.0f;
+    const uint32_t axis = uint32_t(kn);
+    std::memcpy(&rec[7], &axis, 4);
+    return true;
+}
+
 // A sphere of a flat world that nothing else reaches into: every other primitive of the list
 // keeps at least the radius away from its centre (a rectangle by its true distance, other quads
 // by their plane's, spheres by centre distance; any medium or motion in the list says no).  A
@@ -218,6 +250,7 @@ struct Plan {
     std::vector<float> quads;   // 16 floats per quad that stays a quad, list order, padded for the scan's read-ahead
     std::vector<float> pairs;   // the same quads two per 32 floats when all are parallelograms
     std::vector<float> boxes;   // 32 floats per recognised box, sorted by class (match_box)
+    std::vector<float> rects;   // 8 floats per rectangle along the world's axes (match_rect), list order
     std::vector<uint32_t> other; // refs of everything that is not a quad, list order
     std::vector<uint32_t> alone_spheres; // refs of spheres nothing else reaches into (sphere_is_alone)
     uint32_t n_quads = 0, n_boxes_aligned = 0, n_boxes_upright = 0;
@@ -291,6 +324,36 @@ inline std::string plan(const rt_scene_desc *s, Plan &out) {
                     flat_quad_refs.erase(flat_quad_refs.begin(), flat_quad_refs.begin() + n_faces);
                     flat_quads.erase(flat_quads.begin(), flat_quads.begin() + size_t(n_faces) * 16);
                     break;
+                }
+                // Rectangles along the world's axes leave the quad records too.  The scan tests them after
+                // the quads that stay quads and before the boxes, in list order among themselves: the
+                // list's own tie order, unless a quad that stays a quad comes later in the list and
+                // lies in the rectangle's plane -- then the rectangle stays a quad as well.
+                {
+                    std::vector<char> take(flat_quad_refs.size(), 0);
+                    for (size_t i = flat_quad_refs.size(); i-- > 0;) {
+                        const rt_quad *me = &s->quads[flat_quad_refs[i] & RT_REF_INDEX_MASK];
+                        float rec[8];
+                        if (!match_rect(*me, flat_quad_refs[i], rec)) continue;
+                        bool tie_order_kept = true;
+                        for (size_t j = i + 1; j < flat_quad_refs.size(); ++j)
+                            if (!take[j] && quad_in_a_face_plane(s->quads[flat_quad_refs[j] & RT_REF_INDEX_MASK], &me, 1)) tie_order_kept = false;
+                        take[i] = tie_order_kept;
+                    }
+                    std::vector<float> kept_quads;
+                    std::vector<uint32_t> kept_refs;
+                    for (size_t i = 0; i < flat_quad_refs.size(); ++i) {
+                        if (take[i]) {
+                            float rec[8];
+                            (void)match_rect(s->quads[flat_quad_refs[i] & RT_REF_INDEX_MASK], flat_quad_refs[i], rec);
+                            out.rects.insert(out.rects.end(), rec, rec + 8);
+                        } else {
+                            kept_quads.insert(kept_quads.end(), flat_quads.begin() + 16 * i, flat_quads.begin() + 16 * (i + 1));
+                            kept_refs.push_back(flat_quad_refs[i]);
+                        }
+                    }
+                    flat_quads.swap(kept_quads);
+                    flat_quad_refs.swap(kept_refs);
                 }
                 // The scan runs the box classes one after the other (aligned, upright, general), and
                 // between boxes too a later one wins a tie.  When the list's own order is another, every

@@ -541,21 +541,22 @@ def _flat_plan(sb):
     info = _ffi.RtAccelInfo()
     assert lib.rt_accel_selftest(sb.flatten(), _ffi.RT_BUILD_AUTO, C.byref(info), err, 512) == 0, err.value
     return dict(quads=info.flat_quads, boxes=info.flat_boxes, aligned=info.flat_boxes_aligned, upright=info.flat_boxes_upright,
-                alone=info.flat_alone_spheres)
+                alone=info.flat_alone_spheres, rects=info.flat_rects)
 
 
 def test_flat_world_plan_recognises_rooms_and_boxes_without_a_gpu():
     """The records of the flat scan are planned on the host: the five walls of cornell_box.toml are a
-    room along the world axes, box3 under RotateY + Translate is an upright box, the lamp stays a
-    quad; a list that orders its boxes against the class order keeps general frames; a quad in a
-    wall's plane later in the list keeps the walls quads (it would take ties from the wall); a BVH
-    world plans nothing."""
+    room along the world axes, box3 under RotateY + Translate is an upright box, the lamp is a
+    rectangle along the world's axes; a list that orders its boxes against the class order keeps
+    general frames; a quad in a wall's plane later in the list keeps the walls from being a room (it
+    would take ties from the wall) -- walls, poster and lamp are then rectangles in list order, and
+    a tilted poster that stays a quad keeps the wall under it a quad too; a BVH world plans nothing."""
     sb = ra.SceneBuilder()
     ra.scenes.cornell_main(sb)
-    assert _flat_plan(sb) == dict(quads=1, boxes=3, aligned=1, upright=2, alone=0)
+    assert _flat_plan(sb) == dict(quads=0, rects=1, boxes=3, aligned=1, upright=2, alone=0)
     sb = ra.SceneBuilder()
     ra.scenes.cornell_book3(sb)
-    assert _flat_plan(sb) == dict(quads=1, boxes=2, aligned=1, upright=1, alone=1)
+    assert _flat_plan(sb) == dict(quads=0, rects=1, boxes=2, aligned=1, upright=1, alone=1)
 
     def world(order, poster=False, tilt=None):
         sb = ra.SceneBuilder()
@@ -568,9 +569,9 @@ def test_flat_world_plan_recognises_rooms_and_boxes_without_a_gpu():
         sb.set_world(sb.list(objs))
         sb.set_lights(lamp)
         return sb
-    assert _flat_plan(world("au")) == dict(quads=2, boxes=2, aligned=1, upright=1, alone=0)
-    assert _flat_plan(world("ua")) == dict(quads=2, boxes=2, aligned=0, upright=0, alone=0)  # general frames, list order
-    assert _flat_plan(world("u")) == dict(quads=2, boxes=1, aligned=0, upright=1, alone=0)
+    assert _flat_plan(world("au")) == dict(quads=0, rects=2, boxes=2, aligned=1, upright=1, alone=0)
+    assert _flat_plan(world("ua")) == dict(quads=0, rects=2, boxes=2, aligned=0, upright=0, alone=0)  # general frames, list order
+    assert _flat_plan(world("u")) == dict(quads=0, rects=2, boxes=1, aligned=0, upright=1, alone=0)
     # a poster on the back wall of the Cornell room
     sb = ra.SceneBuilder()
     objs = [sb.load_toml(ra.scenes.cornell_toml_text())]
@@ -578,10 +579,20 @@ def test_flat_world_plan_recognises_rooms_and_boxes_without_a_gpu():
     lamp = sb.quad((343.0, 554.0, 332.0), (-130.0, 0.0, 0.0), (0.0, 0.0, -105.0), sb.light((20.0, 20.0, 20.0)))
     sb.set_world(sb.list(objs + [poster, lamp]))
     sb.set_lights(lamp)
-    assert _flat_plan(sb) == dict(quads=7, boxes=0, aligned=0, upright=0, alone=0)
+    assert _flat_plan(sb) == dict(quads=0, rects=7, boxes=0, aligned=0, upright=0, alone=0)
+    # a parallelogram (not a rectangle) in the floor's plane, later in the list than the floor: it
+    # stays a quad, and so does the floor, which it takes ties from; the lamp between them does not care
+    sb = ra.SceneBuilder()
+    white = sb.lambertian((0.7, 0.7, 0.7))
+    floor = sb.quad((-6, 0, -6), (12, 0, 0), (0, 0, 12), white)
+    lamp = sb.quad((-1, 7.9, -1), (2, 0, 0), (0, 0, 2), sb.light((9.0, 9.0, 9.0)))
+    rug = sb.quad((-1, 0, -1), (2, 0, 0.5), (0, 0, 2), white)
+    sb.set_world(sb.list([floor, lamp, rug]))
+    sb.set_lights(lamp)
+    assert _flat_plan(sb) == dict(quads=2, rects=1, boxes=0, aligned=0, upright=0, alone=0)
     sb = ra.SceneBuilder()
     ra.scenes.book1_final(sb, grid=3)
-    assert _flat_plan(sb) == dict(quads=0, boxes=0, aligned=0, upright=0, alone=0)
+    assert _flat_plan(sb) == dict(quads=0, rects=0, boxes=0, aligned=0, upright=0, alone=0)
 
 
 def test_scene_file_camera_antialiasing_round_trip():
