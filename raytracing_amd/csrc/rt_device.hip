@@ -770,7 +770,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.n_flat_quads = fp.n_quads; // (the array is padded with records that cannot hit)
     d.n_flat_other = uint32_t(flat_other.size());
     d.n_flat_boxes = uint32_t(fp.boxes.size() / 32);
-    d.n_flat_rects = uint32_t(fp.rects.size() / 8);
+    d.n_flat_rects = uint32_t(fp.rects.size() / 8), d.n_flat_rects_x = fp.n_rects_x, d.n_flat_rects_y = fp.n_rects_y;
     d.n_flat_boxes_aligned = fp.n_boxes_aligned, d.n_flat_boxes_upright = fp.n_boxes_upright;
     if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, spheres.data(), spheres.size(), &ds) ||

@@ -170,7 +170,8 @@ inline bool quad_in_a_face_plane(const rt_quad &other, const rt_quad *const *fac
 // quad test (hittable.rs:341-371) then needs no dot products: t = (plane - o_n) * rcp(d_n), and
 // alpha, beta are one coordinate of the hit point each, scaled -- the same arithmetic the packed quad
 // test does with the zeros left out, bit for bit.  The inside rule 0 <= alpha, beta <= 1 does not tell
-// the two edges apart, so the in-plane axes are stored in ascending order.
+// the two edges apart, so the in-plane axes are stored in ascending order.  Rectangles in one plane
+// have one normal axis, so sorting the records by that axis keeps the list's order where ties arise.
 //   record, 8 floats: plane, Q_a, Q_b, 1/extent_a (signed), 1/extent_b (signed), ref, -, normal axis
 inline bool match_rect(const rt_quad &q, uint32_t ref, float rec[8]) {
 #ifdef RT_NO_RECTS // experiments: every such rectangle stays a quad
@@ -250,7 +251,8 @@ struct Plan {
     std::vector<float> quads;   // 16 floats per quad that stays a quad, list order, padded for the scan's read-ahead
     std::vector<float> pairs;   // the same quads two per 32 floats when all are parallelograms
     std::vector<float> boxes;   // 32 floats per recognised box, sorted by class (match_box)
-    std::vector<float> rects;   // 8 floats per rectangle along the world's axes (match_rect), list order
+    std::vector<float> rects;   // 8 floats per rectangle along the world's axes (match_rect): by normal axis, then list order
+    uint32_t n_rects_x = 0, n_rects_y = 0; // of rects: normal along x (they come first), along y (next); the rest along z
     std::vector<uint32_t> other; // refs of everything that is not a quad, list order
     std::vector<uint32_t> alone_spheres; // refs of spheres nothing else reaches into (sphere_is_alone)
     uint32_t n_quads = 0, n_boxes_aligned = 0, n_boxes_upright = 0;
@@ -340,18 +342,22 @@ inline std::string plan(const rt_scene_desc *s, Plan &out) {
                             if (!take[j] && quad_in_a_face_plane(s->quads[flat_quad_refs[j] & RT_REF_INDEX_MASK], &me, 1)) tie_order_kept = false;
                         take[i] = tie_order_kept;
                     }
-                    std::vector<float> kept_quads;
+                    std::vector<float> kept_quads, by_axis[3]; // the scan runs one loop per normal axis
                     std::vector<uint32_t> kept_refs;
                     for (size_t i = 0; i < flat_quad_refs.size(); ++i) {
                         if (take[i]) {
                             float rec[8];
                             (void)match_rect(s->quads[flat_quad_refs[i] & RT_REF_INDEX_MASK], flat_quad_refs[i], rec);
-                            out.rects.insert(out.rects.end(), rec, rec + 8);
+                            uint32_t axis;
+                            std::memcpy(&axis, &rec[7], 4);
+                            by_axis[axis].insert(by_axis[axis].end(), rec, rec + 8);
                         } else {
                             kept_quads.insert(kept_quads.end(), flat_quads.begin() + 16 * i, flat_quads.begin() + 16 * (i + 1));
                             kept_refs.push_back(flat_quad_refs[i]);
                         }
                     }
+                    for (int a = 0; a < 3; ++a) out.rects.insert(out.rects.end(), by_axis[a].begin(), by_axis[a].end());
+                    out.n_rects_x = uint32_t(by_axis[0].size() / 8), out.n_rects_y = uint32_t(by_axis[1].size() / 8);
                     flat_quads.swap(kept_quads);
                     flat_quad_refs.swap(kept_refs);
                 }

@@ -84,7 +84,9 @@ struct DScene {
     const float4 *nodes4;
     uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_pairs, n_flat_other, n_nodes4, n_flat_boxes;
     uint32_t n_flat_boxes_aligned, n_flat_boxes_upright; // the box records' first two classes (scan_flat)
-    uint32_t n_flat_rects; // rectangles along the world's axes: 8 floats each at the head of flat_boxes, padded to 32
+    // rectangles along the world's axes: 8 floats each at the head of flat_boxes, padded to 32; sorted
+    // by normal axis: the first _x have it along x, the next _y along y, the rest along z
+    uint32_t n_flat_rects, n_flat_rects_x, n_flat_rects_y;
     // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
     uint32_t stack4, lds_nodes4;
 };
@@ -843,17 +845,18 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
     // word read per box would put a second scalar-load round trip into every iteration.
     const RT_CONST_AS float *B = as_uniform(sc.flat_boxes);
     const uint32_t n_boxes = sc.n_flat_boxes, n_aligned = sc.n_flat_boxes_aligned, n_upright = sc.n_flat_boxes_upright;
-    const uint32_t n_rects = sc.n_flat_rects;
-    asm volatile("" ::"s"(B), "s"(n_boxes), "s"(n_aligned), "s"(n_upright), "s"(n_rects)); // one request, one wait
+    const uint32_t n_rects = sc.n_flat_rects, n_rects_x = sc.n_flat_rects_x, n_rects_y = sc.n_flat_rects_y;
+    asm volatile("" ::"s"(B), "s"(n_boxes), "s"(n_aligned), "s"(n_upright), "s"(n_rects), "s"(n_rects_x), "s"(n_rects_y)); // one request, one wait
     // Rectangles along the world's axes (a lamp under a ceiling): the quad test with the zeros of
     // its record left out -- t = (plane - o_n) * rcp(d_n), alpha and beta one coordinate of the hit
     // point each -- which gives the packed quad test's bits, so ties fall as they did.  Records of 8
-    // floats ahead of the box records, in list order: plane, Q_a, Q_b, 1/extent_a, 1/extent_b, ref,
-    // -, normal axis (a < b are the two other axes).  ~17 vector instructions instead of 45 a pair.
+    // floats ahead of the box records: plane, Q_a, Q_b, 1/extent_a, 1/extent_b, ref, -, normal axis
+    // (a < b are the two other axes); sorted by normal axis, list order within one (rectangles in
+    // one plane have one normal axis), one loop per axis.  ~17 vector instructions instead of 45 a pair.
     if (n_rects) {
         auto rect = [&](float on, float dn, float oa, float da, float ob, float db) {
-            // (rounded here, as the quad test's t is: contracted into the comparisons below, the
-            // unrounded product would tell t from an equal t of the same plane and lose the tie)
+            // (t is rounded here, as the quad test's is: contracted into the comparisons below, the
+            // unrounded product would tell it from an equal t of the same plane and lose the tie)
             float t = (B[0] - on) * __builtin_amdgcn_rcpf(dn);
             asm volatile("" : "+v"(t));
             const float a = fmaf(da, t, oa - B[1]) * B[3], b = fmaf(db, t, ob - B[2]) * B[4];
@@ -864,12 +867,10 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
             best.t = ok ? t : best.t;
             best.ref = ok ? r : best.ref;
         };
-        for (uint32_t k = 0; k < n_rects; ++k, B += 8) {
-            const uint32_t axis = fbits(B[7]); // uniform
-            if (axis == 1u) rect(o.y, d.y, o.x, d.x, o.z, d.z);
-            else if (axis == 0u) rect(o.x, d.x, o.y, d.y, o.z, d.z);
-            else rect(o.z, d.z, o.x, d.x, o.y, d.y);
-        }
+        uint32_t k = 0;
+        for (; k < n_rects_x; ++k, B += 8) rect(o.x, d.x, o.y, d.y, o.z, d.z);
+        for (const uint32_t end = k + n_rects_y; k < end; ++k, B += 8) rect(o.y, d.y, o.x, d.x, o.z, d.z);
+        for (; k < n_rects; ++k, B += 8) rect(o.z, d.z, o.x, d.x, o.y, d.y);
         B += 8 * ((0u - n_rects) & 3u); // the box records start on a 128-byte boundary
     }
     if (n_boxes) {

@@ -83,6 +83,7 @@ bool load_and_build(const std::string &text, const std::string &base, bool scene
                     for (uint32_t k = 0; k < root.count; ++k) list_quads += (desc->refs[root.left + k] >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD;
                     check(fp.n_quads + fp.rects.size() / 8 + quads_in_boxes == list_quads, "flat::plan: quads of the list not accounted for once");
                     check(fp.n_boxes_aligned + fp.n_boxes_upright <= fp.boxes.size() / 32, "flat::plan: class counts");
+                    check(fp.n_rects_x + fp.n_rects_y <= fp.rects.size() / 8, "flat::plan: rectangle axis counts");
                 }
             }
             for (uint32_t builder : {uint32_t(RT_BUILD_REFERENCE), uint32_t(RT_BUILD_SAH)}) {
