@@ -220,7 +220,7 @@ __device__ __forceinline__ SphereEq sphere_eq(float4 s0, float4 s1, V3 o, V3 d, 
     q.center = fma3(mk(s1), time, mk(s0));
     q.r = s0.w, q.pr = q.r * q.r;
     q.a = len2(d);
-    q.inv_a = 1.0f / q.a;
+    q.inv_a = rcp(q.a); // v_rcp_f32, 1 ulp (the compiler's 1/x costs ten instructions here)
     q.oc = q.center - o;
     q.h = dot(d, q.oc);
     q.b2 = len2(q.oc);
@@ -252,8 +252,10 @@ __device__ __forceinline__ bool sphere_roots(const SphereEq &q, V3 o, V3 d, floa
         disc = fmaf(h, h, -(q.a * c)); // |c| << r^2 here: this form is the well-conditioned one
     }
     if (disc < 0.0f) return false;
-    const float w = h + copysignf(sqrtf(disc), h);
-    const float ta = c / w, tb = w * q.inv_a;
+    // v_sqrt_f32 and v_rcp_f32 as they are (1 ulp each): the compiler's sqrtf and / wrap them in range
+    // scaling, six instructions apiece, for arguments that do not occur here
+    const float w = h + copysignf(fsqrt(disc), h);
+    const float ta = c * rcp(w), tb = w * q.inv_a;
     t_near = fminf(ta, tb), t_far = fmaxf(ta, tb);
     return true;
 }
