@@ -769,13 +769,14 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.n_flat_pairs = uint32_t(flat_pairs.size() / 32);
     d.n_flat_quads = fp.n_quads; // (the array is padded with records that cannot hit)
     d.n_flat_other = uint32_t(flat_other.size());
+    d.n_flat_spheres = uint32_t(fp.spheres.size() / 16);
     d.n_flat_boxes = uint32_t(fp.boxes.size() / 32);
     d.n_flat_rects = uint32_t(fp.rects.size() / 8), d.n_flat_rects_x = fp.n_rects_x, d.n_flat_rects_y = fp.n_rects_y;
     d.n_flat_boxes_aligned = fp.n_boxes_aligned, d.n_flat_boxes_upright = fp.n_boxes_upright;
     if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, spheres.data(), spheres.size(), &ds) ||
         upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || (h->accel == ACCEL_BVH4Q ? upload(h, nodes4q.data(), nodes4q.size(), &dn4q) : upload(h, nodes4.data(), nodes4.size(), &dn4)) ||
-        upload(h, flat_other.data(), flat_other.size(), &d.flat_other) ||
+        upload(h, flat_other.data(), flat_other.size(), &d.flat_other) || upload(h, fp.spheres.data(), fp.spheres.size(), &d.flat_spheres) ||
         upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
         upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) ||
         upload(h, s->texels, s->n_texel_bytes, &d.texels) || upload(h, s->noise_vec, size_t(s->n_noise) * 1024, &dnv) ||

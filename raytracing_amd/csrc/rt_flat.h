@@ -254,6 +254,8 @@ struct Plan {
     std::vector<float> rects;   // 8 floats per rectangle along the world's axes (match_rect): by normal axis, then list order
     uint32_t n_rects_x = 0, n_rects_y = 0; // of rects: normal along x (they come first), along y (next); the rest along z
     std::vector<uint32_t> other; // refs of everything that is not a quad, list order
+    std::vector<float> spheres; // when everything that is not a quad is a sphere: 16 floats per sphere (centre, radius,
+                                // centre's velocity, material, ref, 7 unused), list order, and `other` is left empty
     std::vector<uint32_t> alone_spheres; // refs of spheres nothing else reaches into (sphere_is_alone)
     uint32_t n_quads = 0, n_boxes_aligned = 0, n_boxes_upright = 0;
 };
@@ -385,6 +387,22 @@ inline std::string plan(const rt_scene_desc *s, Plan &out) {
                 for (uint32_t r : list)
                     if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE && sphere_is_alone(s, list, r)) out.alone_spheres.push_back(r);
             }
+        }
+    }
+    // Spheres only among the rest (no medium): their records in list order, so that the scan reads a
+    // sphere with one request instead of a ref, a decision on its kind and then the record.
+    {
+        bool all_spheres = !flat_other.empty();
+        for (uint32_t r : flat_other) all_spheres = all_spheres && (r >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE;
+        if (all_spheres) {
+            for (uint32_t r : flat_other) {
+                const rt_sphere &sp = s->spheres[r & RT_REF_INDEX_MASK];
+                float rec[16] = {sp.c0[0], sp.c0[1], sp.c0[2], sp.radius, sp.cv[0], sp.cv[1], sp.cv[2]};
+                std::memcpy(&rec[7], &sp.mat, 4);
+                std::memcpy(&rec[8], &r, 4);
+                out.spheres.insert(out.spheres.end(), rec, rec + 16);
+            }
+            flat_other.clear();
         }
     }
     // parallelograms only: the same records two per 32 floats, fields interleaved

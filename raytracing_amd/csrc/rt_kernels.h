@@ -76,6 +76,7 @@ struct DScene {
     const float *flat_quads;
     const float *flat_pairs; // the same quads two per record when all are parallelograms (see scan_flat)
     const uint32_t *flat_other;
+    const float *flat_spheres; // when all of flat_other would be spheres: their records, 16 floats each (see scan_flat)
     // runs of six quads at the end of the list's quads that are the faces of one rectangular box
     // (box3, hittable.rs:398-455, under any rigid map): 32 floats each, see scan_flat
     const float *flat_boxes;
@@ -87,6 +88,7 @@ struct DScene {
     // rectangles along the world's axes: 8 floats each at the head of flat_boxes, padded to 32; sorted
     // by normal axis: the first _x have it along x, the next _y along y, the rest along z
     uint32_t n_flat_rects, n_flat_rects_x, n_flat_rects_y;
+    uint32_t n_flat_spheres;
     // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
     uint32_t stack4, lds_nodes4;
 };
@@ -928,6 +930,16 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
                     axis(2, od[2], dd[2], __builtin_amdgcn_rcpf(dd[2])));
         }
     }
+    // the rest of the list: spheres by their packed records when there is nothing else, or by reference
+    const RT_CONST_AS float *S = as_uniform(sc.flat_spheres);
+    for (uint32_t k = 0; k < sc.n_flat_spheres; ++k, S += 16) {
+        const float4 s0 = make_float4(S[0], S[1], S[2], S[3]), s1 = make_float4(S[4], S[5], S[6], S[7]);
+        const uint32_t r = fbits(S[8]);
+        float t;
+        const bool h = hit_sphere(s0, s1, o, d, time, tlo, best.t, r == origin_ref, t);
+        best.t = h ? t : best.t;
+        best.ref = h ? r : best.ref;
+    }
     const RT_CONST_AS uint32_t *other = as_uniform(sc.flat_other);
     for (uint32_t k = 0; k < sc.n_flat_other; ++k) test_prim<true>(sc, other[k], o, d, time, tlo, origin_ref, rc, best);
 }
@@ -1491,7 +1503,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(Queue q, const DScene *scp, con
     const uint32_t n = q.count[chunk];
     if (n == 0) return;
     const size_t cbase = size_t(chunk) * q.cap;
-    const bool flat_world = (sc.n_flat_pairs | sc.n_flat_quads | sc.n_flat_other | sc.n_flat_boxes | sc.n_flat_rects) != 0; // hits may come from the flat scan
+    const bool flat_world = (sc.n_flat_pairs | sc.n_flat_quads | sc.n_flat_other | sc.n_flat_boxes | sc.n_flat_rects | sc.n_flat_spheres) != 0; // hits may come from the flat scan
     uint32_t out = 0; // survivors written so far; always <= base, so writes never pass reads
     for (uint32_t base = 0; base < n; base += WAVE) {
         const uint32_t k = base + lane;
