@@ -1769,13 +1769,23 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     __shared__ RegroupPool s_pool[BLOCK / WAVE];
     __shared__ float4 s_quad_nm[TABLES ? TABLE_QUADS : 1], s_spheres[TABLES ? 3 * TABLE_SPHERES : 1];
     __shared__ rt_material s_mats[TABLES ? TABLE_MATERIALS : 1];
-    if (TABLES) { // the only barrier of the kernel: before any wave takes its first turn
+    __shared__ uint8_t s_next[TABLES ? TABLE_QUADS + TABLE_SPHERES + 8 : 1];
+    if (TABLES) { // the only barriers of the kernel: before any wave takes its first turn
         for (uint32_t i = threadIdx.x; i < n_quads; i += BLOCK) {
             const float4 q1 = sc.quads[6 * i + 1];
             s_quad_nm[i] = make_float4(q1.x, q1.y, q1.z, sc.quads[6 * i + 3].w);
         }
         for (uint32_t i = threadIdx.x; i < 3 * n_spheres; i += BLOCK) s_spheres[i] = sc.spheres[i];
         for (uint32_t i = threadIdx.x; i < n_mats; i += BLOCK) s_mats[i] = sc.mats[i];
+        __syncthreads();
+        // the list a path joins after a hit on quad i / sphere i, by its material's kind; the last entry is a miss
+        auto list_of = [&](uint32_t mat_id) {
+            const uint32_t type = s_mats[mat_id].type;
+            return uint8_t(type == RT_MAT_LIGHT ? RG_END : (type == RT_MAT_METAL ? RG_METAL : (type == RT_MAT_DIELECTRIC ? RG_GLASS : RG_DIFFUSE)));
+        };
+        for (uint32_t i = threadIdx.x; i < n_quads; i += BLOCK) s_next[i] = list_of(fbits(s_quad_nm[i].w));
+        for (uint32_t i = threadIdx.x; i < n_spheres; i += BLOCK) s_next[TABLE_QUADS + i] = list_of(fbits(s_spheres[3 * i + 1].w));
+        if (threadIdx.x == 0) s_next[TABLE_QUADS + TABLE_SPHERES] = uint8_t(RG_END);
         __syncthreads();
     }
     const FlatTables tb{s_quad_nm, s_spheres, s_mats};
@@ -1907,7 +1917,13 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 scan_flat(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
                 // the material's kind decides where the path waits next; a miss ends it like a light
                 uint32_t type = RT_MAT_LIGHT;
-                if (best.ref != RT_REF_NONE) {
+                bool looked_up = false;
+                if (TABLES && !has_media) { // one table read by (kind, index); a miss reads the table's last entry
+                    const uint32_t pk = best.ref >> RT_REF_KIND_SHIFT, idx = best.ref & RT_REF_INDEX_MASK;
+                    const uint32_t at = best.ref == RT_REF_NONE ? TABLE_QUADS + TABLE_SPHERES : (pk == RT_KIND_SPHERE ? TABLE_QUADS + idx : idx);
+                    kind = s_next[at];
+                    looked_up = true;
+                } else if (best.ref != RT_REF_NONE) {
                     const uint32_t pk = best.ref >> RT_REF_KIND_SHIFT, idx = best.ref & RT_REF_INDEX_MASK;
                     uint32_t mat_id;
                     if (TABLES) {
@@ -1921,8 +1937,9 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 const V3 p = fma3(mk(rb), best.t, mk(ra)); // as shade_emit forms it
                 pool.ra[slot] = make_float4(p.x, p.y, p.z, ra.w);
                 pool.rb[slot].w = bitsf(best.ref);
-                kind = type == RT_MAT_LIGHT ? RG_END
-                                            : (type == RT_MAT_METAL ? RG_METAL : (type == RT_MAT_DIELECTRIC ? RG_GLASS : RG_DIFFUSE));
+                if (!looked_up)
+                    kind = type == RT_MAT_LIGHT ? RG_END
+                                                : (type == RT_MAT_METAL ? RG_METAL : (type == RT_MAT_DIELECTRIC ? RG_GLASS : RG_DIFFUSE));
             }
             push(RG_DIFFUSE, n_diffuse, kind == RG_DIFFUSE, slot);
             push(RG_END, n_end, kind == RG_END, slot);
