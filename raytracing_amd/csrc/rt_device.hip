@@ -263,6 +263,9 @@ int validate_scene(rt_handle *h, const rt_scene_desc *s) {
         // only Parallelogram implements pdf_value / random (hittable.rs:377-395)
         if ((lr >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD && s->quads[lr & RT_REF_INDEX_MASK].shape != RT_SHAPE_PARALLELOGRAM)
             return fail(h, "rt_upload_scene: a quad light must be a parallelogram");
+        // (the light records tell a sphere by its radius)
+        if ((lr >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE && !(s->spheres[lr & RT_REF_INDEX_MASK].radius > 0.0f))
+            return fail(h, "rt_upload_scene: a sphere light needs a positive radius");
     }
     return 0;
 }
@@ -707,6 +710,22 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     std::vector<float> flat_boxes(fp.rects);
     flat_boxes.resize((flat_boxes.size() + 31) / 32 * 32, 0.0f);
     flat_boxes.insert(flat_boxes.end(), fp.boxes.begin(), fp.boxes.end());
+    // the light list's primitives, one record per light in list order (light_random in rt_kernels.h)
+    std::vector<float> light_recs(size_t(s->n_lights) * 32, 0.0f);
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        float *L = &light_recs[size_t(i) * 32];
+        const uint32_t lr = s->light_refs[i], idx = lr & RT_REF_INDEX_MASK;
+        if ((lr >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
+            const rt_quad &q = s->quads[idx];
+            for (int a = 0; a < 3; ++a) L[a] = q.q[a], L[4 + a] = q.n[a], L[8 + a] = q.avec[a], L[12 + a] = q.bvec[a], L[16 + a] = q.u[a], L[20 + a] = q.v[a];
+            L[7] = q.area;
+        } else {
+            const rt_sphere &sp = s->spheres[idx];
+            for (int a = 0; a < 3; ++a) L[a] = sp.c0[a];
+            L[3] = sp.radius;
+        }
+    }
+    const float *d_light_recs = nullptr;
     // device copy of the spheres: pad = 1 marks a sphere of a flat world that nothing reaches into
     std::vector<rt_sphere> spheres(s->spheres, s->spheres + s->n_spheres);
     for (rt_sphere &sp : spheres) sp.pad = 0;
@@ -778,11 +797,12 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
         upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || (h->accel == ACCEL_BVH4Q ? upload(h, nodes4q.data(), nodes4q.size(), &dn4q) : upload(h, nodes4.data(), nodes4.size(), &dn4)) ||
         upload(h, flat_other.data(), flat_other.size(), &d.flat_other) || upload(h, fp.spheres.data(), fp.spheres.size(), &d.flat_spheres) ||
         upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
-        upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) ||
+        upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) || upload(h, light_recs.data(), light_recs.size(), &d_light_recs) ||
         upload(h, s->texels, s->n_texel_bytes, &d.texels) || upload(h, s->noise_vec, size_t(s->n_noise) * 1024, &dnv) ||
         upload(h, s->noise_perm, size_t(s->n_noise) * 768, &d.noise_perm))
         return rollback();
     d.quads = reinterpret_cast<const float4 *>(dq);
+    d.light_recs = reinterpret_cast<const float4 *>(d_light_recs);
     d.spheres = reinterpret_cast<const float4 *>(ds);
     d.noise_vec = reinterpret_cast<const float4 *>(dnv);
     d.nodes4 = h->accel == ACCEL_BVH4Q ? reinterpret_cast<const float4 *>(dn4q) : reinterpret_cast<const float4 *>(dn4);

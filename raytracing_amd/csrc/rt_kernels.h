@@ -68,6 +68,7 @@ struct DScene {
     const rt_material *mats;
     const rt_texture *texs;
     const uint32_t *light_refs;
+    const float4 *light_recs; // the light list's primitives, 8 float4 per light (see light_random)
     const uint8_t *texels;
     const float4 *noise_vec;
     const int *noise_perm;
@@ -1037,26 +1038,30 @@ struct FlatTables {
     const float4 *spheres;    // as DScene::spheres
     const rt_material *mats;
 };
-// direction to a random point of light `r`, unnormalised (Parallelogram::random), or towards
-// the visible cap of a sphere
-// UNIFORM: r is the same in every lane, so the light's record comes through scalar loads.
+// The light list, one record of 8 float4 per light in list order, made at upload from the lights'
+// primitives so that sampling and the pdf read a light with one request (by reference it was two
+// dependent ones: the ref, then the primitive):
+//   L0 = Q | radius 0        or  centre | radius (> 0: a sphere)
+//   L1 = n | area   L2 = avec   L3 = bvec   L4 = u   L5 = v   (parallelograms; the only quad shape
+//   with pdf_value and random, hittable.rs:99-107, 377-395)
+// Direction to a random point of light i, unnormalised (Parallelogram::random), or towards the
+// visible cap of a sphere.  UNIFORM: i is the same in every lane, so the record comes through scalar loads.
 template <bool UNIFORM>
-__device__ __forceinline__ V3 light_random(SceneRef sc, uint32_t r, V3 p, Rng &rng) {
-    uint32_t idx = r & RT_REF_INDEX_MASK;
-    if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
-        const float4 *Q = sc.quads + 6 * idx;
+__device__ __forceinline__ V3 light_random(SceneRef sc, uint32_t i, V3 p, Rng &rng) {
+    const float4 *L = sc.light_recs + 8 * size_t(i);
+    const float4 l0 = load4<UNIFORM>(L, 0), lu = load4<UNIFORM>(L, 4), lv = load4<UNIFORM>(L, 5); // one round trip
+    if (!(l0.w > 0.0f)) {
         float a = rng.next();
         float b = rng.next();
-        V3 lp = fma3(mk(load4<UNIFORM>(Q, 5)), b, fma3(mk(load4<UNIFORM>(Q, 4)), a, mk(load4<UNIFORM>(Q, 0))));
+        V3 lp = fma3(mk(lv), b, fma3(mk(lu), a, mk(l0)));
         return lp - p;
     }
-    float4 s0 = load4<UNIFORM>(sc.spheres + 3 * idx, 0);
-    V3 dir = mk(s0) - p;
+    V3 dir = mk(l0) - p;
     float dist2 = len2(dir);
     ONB uvw(dir);
     float r1 = rng.next();
     float r2 = rng.next();
-    float z = 1.0f + r2 * (fsqrt(1.0f - s0.w * s0.w * rcp(dist2)) - 1.0f);
+    float z = 1.0f + r2 * (fsqrt(1.0f - l0.w * l0.w * rcp(dist2)) - 1.0f);
     float sn = __builtin_amdgcn_sinf(r1), cs = __builtin_amdgcn_cosf(r1);
     float s = fsqrt(fmaxf(0.f, 1.0f - z * z));
     return uvw.transform(V3{cs * s, sn * s, z});
@@ -1064,13 +1069,11 @@ __device__ __forceinline__ V3 light_random(SceneRef sc, uint32_t r, V3 p, Rng &r
 
 // Parallelogram::pdf_value (hittable.rs:377-389) / sphere cone pdf
 template <bool UNIFORM>
-__device__ __forceinline__ float light_pdf(SceneRef sc, uint32_t r, V3 p, V3 dir) {
-    uint32_t idx = r & RT_REF_INDEX_MASK;
-    if ((r >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD) {
-        // a light quad is a Parallelogram (only that shape implements pdf_value, and the upload
-        // of a scene holds lights to it): the plane test of hit_quad without the shape cases
-        const float4 *Q = sc.quads + 6 * idx;
-        const float4 q0 = load4<UNIFORM>(Q, 0), q1 = load4<UNIFORM>(Q, 1), q2 = load4<UNIFORM>(Q, 2), q3 = load4<UNIFORM>(Q, 3);
+__device__ __forceinline__ float light_pdf(SceneRef sc, uint32_t i, V3 p, V3 dir) {
+    const float4 *L = sc.light_recs + 8 * size_t(i);
+    const float4 q0 = load4<UNIFORM>(L, 0), q1 = load4<UNIFORM>(L, 1), q2 = load4<UNIFORM>(L, 2), q3 = load4<UNIFORM>(L, 3);
+    if (!(q0.w > 0.0f)) {
+        // the plane test of hit_quad without the shape cases
         const float denom = dot(mk(q1), dir);
         const V3 qo = mk(q0) - p;
         const float t = dot(mk(q1), qo) * rcp(denom);
@@ -1084,7 +1087,7 @@ __device__ __forceinline__ float light_pdf(SceneRef sc, uint32_t r, V3 p, V3 dir
     // Only hit or miss matters here, for an origin away from the light: the quadratic about the
     // point of closest approach, disc/a = r^2 - |oc - (h/a) d|^2, without the compensated terms
     // of hit_sphere.  A root lies in (0.001, inf) iff the far root does.
-    const float4 s0 = load4<UNIFORM>(sc.spheres + 3 * idx, 0);
+    const float4 s0 = q0;
     const V3 oc = mk(s0) - p; // pdf_value asks at time 0 (hittable.rs:378)
     const float a = len2(dir), h = dot(dir, oc), ia = rcp(a);
     const float disc = fmaf(s0.w, s0.w, -len2(fma3(dir, -(h * ia), oc)));
@@ -1097,15 +1100,14 @@ __device__ __forceinline__ float light_pdf(SceneRef sc, uint32_t r, V3 p, V3 dir
 __device__ __forceinline__ V3 lights_random(SceneRef sc, V3 p, Rng &rng) {
     if (sc.lights_kind == RT_LIGHTS_LIST) {
         uint32_t i = uint32_t(rng.next() * float(sc.n_lights));
-        return light_random<false>(sc, sc.light_refs[min(i, sc.n_lights - 1)], p, rng);
+        return light_random<false>(sc, min(i, sc.n_lights - 1), p, rng);
     }
-    return light_random<true>(sc, as_uniform(sc.light_refs)[0], p, rng);
+    return light_random<true>(sc, 0u, p, rng);
 }
 __device__ __forceinline__ float lights_pdf(SceneRef sc, V3 p, V3 dir) {
-    const RT_CONST_AS uint32_t *refs = as_uniform(sc.light_refs);
-    if (sc.lights_kind != RT_LIGHTS_LIST) return light_pdf<true>(sc, refs[0], p, dir);
+    if (sc.lights_kind != RT_LIGHTS_LIST) return light_pdf<true>(sc, 0u, p, dir);
     float w = rcp(float(sc.n_lights)), sum = 0.f;
-    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += w * light_pdf<true>(sc, refs[i], p, dir);
+    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += w * light_pdf<true>(sc, i, p, dir);
     return sum;
 }
 
