@@ -1071,7 +1071,7 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
     RT_HIP(hipStreamSynchronize(h->stream)); // h_ctrl[0] is reused below
 
     const uint32_t k0 = uint32_t(p->seed), k1 = uint32_t(p->seed >> 32);
-    const Film film{h->film, h->film + dc.npix, h->film + 2 * size_t(dc.npix)};
+    const Film film{h->film, dc.npix};
     if (!(p->flags & RT_FLAG_WAVEFRONT)) return render_persistent(h, dc, p, film, total);
 
     // pool geometry: chunks of 512 rays, one wave each

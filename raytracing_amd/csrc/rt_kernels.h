@@ -1287,13 +1287,16 @@ __global__ void __launch_bounds__(BLOCK) k_extend(Queue q, const DScene *scp, ui
     }
 }
 
+// The three planes follow one another in memory: one pointer and the plane size instead of three
+// pointers (the persistent kernels sit at the limit of scalar registers).
 struct Film {
-    float *r, *g, *b;
+    float *base;
+    uint32_t npix;
 };
 __device__ __forceinline__ void film_add(const Film &f, uint32_t pixel, V3 c) {
-    if (c.x != 0.f) atomicAdd(f.r + pixel, c.x);
-    if (c.y != 0.f) atomicAdd(f.g + pixel, c.y);
-    if (c.z != 0.f) atomicAdd(f.b + pixel, c.z);
+    if (c.x != 0.f) atomicAdd(f.base + pixel, c.x);
+    if (c.y != 0.f) atomicAdd(f.base + (pixel + f.npix), c.y);
+    if (c.z != 0.f) atomicAdd(f.base + (pixel + size_t(2) * f.npix), c.z);
 }
 
 // camera.rs:445-453 for one path vertex: what the hit itself contributes.  A miss deposits the
@@ -1796,8 +1799,12 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     for (uint32_t i = lane; i < uint32_t(REGROUP_SLOTS); i += WAVE) pool.list[RG_FREE][i] = uint8_t(i);
     // list lengths, wave-uniform
     uint32_t n_free = REGROUP_SLOTS, n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0, n_end = 0;
+    // The wave owns a range of sample ids: `remaining` of them are left, the next one is (next_pixel,
+    // next_stratum).  `left` is how many the whole frame had left when the wave last asked the counter.
+    // (Counts instead of 64-bit ids: the kernel sits at the limit of scalar registers.)
     const unsigned long long total = ctrl->total_samples;
-    unsigned long long next = 0, end = 0, seen = 0; // sample ids this wave owns; counter value at its last request
+    uint32_t remaining = 0;
+    float left = float(total);
     const float inv_share = 1.0f / (4.0f * float(gridDim.x * (BLOCK / WAVE)));
     uint32_t next_pixel = 0, next_stratum = 0;
     unsigned long long n_seg = 0, n_cam = 0;
@@ -1817,21 +1824,20 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     // is used up): lanes below the returned count make their camera ray (camera.rs:409-430) in
     // `slot`, which joins the rays to trace
     auto new_paths = [&](uint32_t want, uint32_t slot) -> uint32_t {
-        if (next == end && !exhausted) {
-            const float left = float(total > seen ? total - seen : 0ull);
+        if (remaining == 0 && !exhausted) {
             uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
             take = take < MIN_TAKE_FLAT ? MIN_TAKE_FLAT : (take & ~uint32_t(WAVE - 1));
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&ctrl->next_sample, static_cast<unsigned long long>(take));
             b = wave_first(b);
-            seen = b;
-            next = b < total ? b : total;
-            end = b + take < total ? b + take : total;
-            exhausted = next == end;
-            next_pixel = uint32_t(next % cam.npix);
-            next_stratum = cam.stratum_begin + uint32_t(next / cam.npix);
+            left = float(total > b ? total - b : 0ull);
+            const unsigned long long first = b < total ? b : total, last = b + take < total ? b + take : total;
+            remaining = uint32_t(last - first);
+            exhausted = remaining == 0;
+            next_pixel = uint32_t(first % cam.npix);
+            next_stratum = cam.stratum_begin + uint32_t(first / cam.npix);
         }
-        const uint32_t m = uint32_t(end - next < want ? end - next : want);
+        const uint32_t m = remaining < want ? remaining : want;
         if (m == 0) return 0;
         if (lane < m) {
             uint32_t px = next_pixel + lane, st = next_stratum;
@@ -1848,7 +1854,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
             pool.list[RG_RAY][n_ray + lane] = uint8_t(slot);
         }
         n_ray += m;
-        next += m;
+        remaining -= m;
         n_cam += m;
         next_pixel += m;
         while (next_pixel >= cam.npix) next_pixel -= cam.npix, ++next_stratum;
