@@ -1805,9 +1805,17 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     const unsigned long long total = ctrl->total_samples;
     uint32_t remaining = 0;
     float left = float(total);
-    const float inv_share = 1.0f / (4.0f * float(gridDim.x * (BLOCK / WAVE)));
     uint32_t next_pixel = 0, next_stratum = 0;
-    unsigned long long n_seg = 0, n_cam = 0;
+    // segments and camera rays since the wave last added them to the frame's totals: 32-bit counts,
+    // handed over at a refill before they can overflow (a range is at most `grab` paths of at most 255 segments)
+    uint32_t n_seg = 0, n_cam = 0;
+    auto hand_over_counts = [&]() {
+        if (lane == 0) {
+            atomicAdd(&ctrl->segments, static_cast<unsigned long long>(n_seg));
+            atomicAdd(&ctrl->camera_rays, static_cast<unsigned long long>(n_cam));
+        }
+        n_seg = n_cam = 0;
+    };
     bool exhausted = false;
 #ifdef RT_REGROUP_STATS
     unsigned long long rg_turns[RG_STATS] = {}, rg_lanes[RG_STATS] = {}, rg_ticks[RG_STATS] = {};
@@ -1825,6 +1833,8 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
     // `slot`, which joins the rays to trace
     auto new_paths = [&](uint32_t want, uint32_t slot) -> uint32_t {
         if (remaining == 0 && !exhausted) {
+            if ((n_seg | n_cam) >> 30) hand_over_counts();
+            const float inv_share = 1.0f / (4.0f * float(gridDim.x * (BLOCK / WAVE)));
             uint32_t take = uint32_t(fminf(left * inv_share, float(grab)));
             take = take < MIN_TAKE_FLAT ? MIN_TAKE_FLAT : (take & ~uint32_t(WAVE - 1));
             unsigned long long b = 0;
@@ -2014,9 +2024,8 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         rg_ticks[rg_stage] += wall_clock64() - rg_t0;
 #endif
     }
+    hand_over_counts();
     if (lane == 0) {
-        atomicAdd(&ctrl->segments, n_seg);
-        atomicAdd(&ctrl->camera_rays, n_cam);
 #ifdef RT_REGROUP_STATS
         for (uint32_t i = 0; i < RG_STATS; ++i)
             atomicAdd(&g_rg_stats[i], rg_turns[i]), atomicAdd(&g_rg_stats[RG_STATS + i], rg_lanes[i]), atomicAdd(&g_rg_stats[2 * RG_STATS + i], rg_ticks[i]);
