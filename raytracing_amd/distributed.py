@@ -25,12 +25,14 @@ def partition_strata(n_strata: int, world_size: int, rank: int):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def init_from_env(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* as torch.distributed.run sets them."""
+def init_from_env(backend=None, single_rank_group=False):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* as torch.distributed.run sets them.
+    single_rank_group: make a process group for one rank too (the film reduce then goes through
+    the backend as it does with more ranks: a rehearsal of the RCCL path on a one-GPU machine)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -88,10 +90,10 @@ def spawn_ranks(argv, world, share_gpu=False, extra_env=None):
 
 
 def reduce_film(film: torch.Tensor, group=None, staging=None):
-    """In-place sum of the per-rank film sums; a no-op on one rank.  A device film under the gloo
-    backend goes through `staging` (a host tensor of the same shape, pinned for speed) or a
-    temporary."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    """In-place sum of the per-rank film sums; a no-op without a process group (a group of one
+    rank still calls the backend).  A device film under the gloo backend goes through `staging` (a
+    host tensor of the same shape, pinned for speed) or a temporary."""
+    if not (dist.is_available() and dist.is_initialized()):
         return film
     if film.is_cuda and dist.get_backend(group) == "gloo":
         host = staging if staging is not None else torch.empty(film.shape, dtype=film.dtype, device="cpu")
@@ -143,8 +145,7 @@ class DistributedRenderer:
             if end > begin:
                 stats = self.dev.render(cam, mode=mode, seed=seed, stratum_begin=begin, stratum_end=end, **render_args)
             if reduce:
-                if (self.staging is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-                        and dist.get_backend() == "gloo"):
+                if (self.staging is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"):
                     self.staging = torch.empty(self.film.shape, dtype=torch.float32, device="cpu", pin_memory=True)
                 reduce_film(self.film, staging=self.staging)
         self.stream.synchronize()

@@ -1,6 +1,8 @@
 """One rank of the multi-rank GPU test (started by tests/test_gpu_distributed.py through
 spawn_ranks): renders its share of the strata of a few consecutive frames through
-DistributedRenderer, all ranks on GPU 0 with the gloo backend, and saves every reduced film."""
+DistributedRenderer, all ranks on GPU 0 with the gloo backend, and saves every reduced film.
+With backend "nccl" (one rank only: RCCL refuses two ranks on one device) the film reduce goes
+through RCCL on the renderer's stream."""
 import sys
 from pathlib import Path
 
@@ -10,13 +12,14 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def main(out_dir, scene, width, spp, seeds):
+def main(out_dir, scene, width, spp, seeds, backend="gloo"):
     import torch
     import torch.distributed as dist
     import raytracing_amd as ra
     from raytracing_amd import distributed as rdist
 
-    rank, world, local = rdist.init_from_env(backend="gloo")
+    rank, world, local = rdist.init_from_env(backend=backend, single_rank_group=backend == "nccl")
+    assert dist.is_initialized() and dist.get_backend() == backend
     assert local == 0
     torch.cuda.set_device(0)
     sb = ra.SceneBuilder()
@@ -28,8 +31,10 @@ def main(out_dir, scene, width, spp, seeds):
     mode = ra.RT_MODE_REF_EXACT if scene == "cornell_main" else ra.RT_MODE_BOOK3
     for seed in seeds:  # consecutive frames into the same film: clear, render and reduce must stay ordered
         film, st = renderer.render(rcam, cam.effective_spp, rank, world, mode, seed=seed)
-        seg = torch.tensor([float(st.segments if st else 0), float(st.camera_rays if st else 0)], dtype=torch.float64)
+        seg = torch.tensor([float(st.segments if st else 0), float(st.camera_rays if st else 0)], dtype=torch.float64,
+                           device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(seg)
+        seg = seg.cpu()
         np.save(Path(out_dir) / f"film_r{rank}_s{seed}.npy", film.cpu().numpy())
         if rank == 0:
             np.save(Path(out_dir) / f"seg_s{seed}.npy", seg.numpy())
@@ -39,4 +44,5 @@ def main(out_dir, scene, width, spp, seeds):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), [int(s) for s in sys.argv[5].split(",")])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), [int(s) for s in sys.argv[5].split(",")],
+         *(sys.argv[6:7]))

@@ -13,14 +13,16 @@ ROOT = Path(__file__).resolve().parent.parent
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("scene,world", [("cornell_book3", 2), ("cornell_main", 3)])
-def test_ranks_sharing_gpu0_reproduce_the_one_rank_render(tmp_path, scene, world):
+@pytest.mark.parametrize("scene,world,backend", [("cornell_book3", 2, "gloo"), ("cornell_main", 3, "gloo"), ("cornell_book3", 1, "nccl")])
+def test_ranks_sharing_gpu0_reproduce_the_one_rank_render(tmp_path, scene, world, backend):
+    """(The last case is one rank with a process group over RCCL: clear, render and the all-reduce
+    of the film run on the renderer's stream through the backend the 8-GPU job uses.)"""
     import raytracing_amd as ra
     from raytracing_amd import distributed as rdist
     seeds = [5, 6, 7]
     width, spp = 96, 25  # 25 strata do not divide evenly over 2 or 3 ranks
     rc = rdist.spawn_ranks([sys.executable, str(ROOT / "tests" / "dist_worker.py"), str(tmp_path), scene, str(width), str(spp),
-                            ",".join(map(str, seeds))], world, share_gpu=True)
+                            ",".join(map(str, seeds)), backend], world, share_gpu=True)
     assert rc == 0
     sb = ra.SceneBuilder()
     cam = getattr(ra.scenes, scene)(sb, width=width, spp=spp)
