@@ -452,10 +452,18 @@ int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &fi
     unsigned long long blocks_needed = (total + per_block - 1) / per_block;
     unsigned long long blocks = (unsigned long long)per_cu * n_cu;
     if (blocks > blocks_needed) blocks = blocks_needed;
+    // every wave's first range of samples comes with the launch (k_paths_regroup): a quarter of an even
+    // share like the ranges the kernel asks for, whole waves of 64, at most 1024; none when the frame is
+    // too small for that
+    const unsigned long long n_waves = blocks * (BLOCK / WAVE);
+    unsigned long long first_take = std::min<unsigned long long>(total / (4 * n_waves), 1024) & ~63ull;
+    if (first_take < MIN_TAKE_FLAT) first_take = MIN_TAKE_FLAT;
+    if (first_take * n_waves > total) first_take = 0;
     Timer tm{h, (p->flags & RT_FLAG_TIME_KERNELS) != 0};
     int e = tm.begin(4);
     kernel<<<dim3(uint32_t(blocks)), dim3(BLOCK), 0, h->stream>>>(h->d_sc, h->d_cam, film, uint32_t(p->seed), uint32_t(p->seed >> 32),
-                                                                 h->d_ctrl, h->has_media, 1024u, h->n_quads, h->n_spheres, h->n_materials);
+                                                                 h->d_ctrl, h->has_media, 1024u, h->n_quads, h->n_spheres, h->n_materials,
+                                                                 uint32_t(first_take));
     tm.end(e);
     RT_HIP(hipGetLastError());
     h->stats.launches[4]++;
