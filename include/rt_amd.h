@@ -28,6 +28,16 @@
 extern "C" {
 #endif
 
+/* ------------------------------------------------------------------ ABI handshake */
+/* The number changes whenever a struct of this header changes its layout or a function its meaning.
+ * A binding compares rt_abi_version() with the RT_ABI_VERSION it was built against before anything
+ * else.  The three structs that have grown over time (rt_render_params, rt_stats, rt_accel_info)
+ * also start with `struct_size`, which the caller sets to its own sizeof of the struct: fields are
+ * only ever appended, so the library reads / writes the part both sides know and refuses what it
+ * cannot interpret (struct_size 0, or parameters from a newer header than the library's). */
+#define RT_ABI_VERSION 3u
+uint32_t rt_abi_version(void);
+
 /* ------------------------------------------------------------------ flat scene layout */
 
 /* 32-bit reference = kind << 29 | index */
@@ -181,8 +191,10 @@ typedef struct {
 #define RT_FLAG_REGROUP 4u
 #define RT_FLAG_NO_REGROUP 8u
 typedef struct {
+    uint32_t struct_size;                /* = sizeof(rt_render_params) of the caller's header */
     uint32_t mode;
     uint32_t flags;
+    uint32_t reserved;                   /* 0 */
     uint64_t seed;
     uint32_t stratum_begin, stratum_end; /* stratum indices sj*sqrt_spp+si; end = 0 means sqrt_spp^2 */
     uint32_t pool_size;                  /* wavefront: rays in flight; 0 = default */
@@ -192,6 +204,8 @@ typedef struct {
 } rt_render_params;
 
 typedef struct {
+    uint32_t struct_size;  /* in: sizeof(rt_stats) of the caller's header; out: bytes the library filled */
+    uint32_t reserved;
     uint64_t segments;     /* closest-hit queries issued (one world.hit at camera.rs:444 each) */
     uint64_t camera_rays;
     uint64_t dropped;      /* samples skipped because their pdf weight was not finite/positive */
@@ -241,6 +255,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *scene);
 #define RT_BUILD_BYTE_BOXES 0x200u
 int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width);
 typedef struct {
+    uint32_t struct_size;   /* in: sizeof(rt_accel_info) of the caller's header; out: bytes the library filled */
     uint32_t kind;          /* 0 = flat list scan, 1 = binary nodes, 2 = 4-wide nodes */
     uint32_t nodes, depth;  /* of the structure searched (depth: wide only) */
     uint32_t stack_entries; /* per-lane traversal stack held in LDS */
@@ -289,16 +304,48 @@ int rt_film_upload(rt_handle *h, const float *rgb, uint32_t width, uint32_t heig
  * Evaluated in f64 on the fp32 sums. */
 int rt_film_quantize(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma);
 /* rt_film_quantize for callers that cannot allocate.  No counterpart in the reference: it is for
- * code under HIP graph capture, tight serving / preview loops and harnesses that forbid
- * hipMalloc.  Same arguments, same bytes.  The packed image is staged in a fixed device array
- * that every GPU holds from library load to process exit (24.9 MB), so the film may have at most
- * RT_NOALLOC_MAX_PIXELS pixels (3840 x 2160); a larger film is refused with an error.  The call
- * makes no hipMalloc / hipFree or other allocating call.  All handles of one GPU share that
- * array: two such calls that overlap on one GPU race, and the array keeps the last call's bytes
+ * tight serving / preview loops and harnesses that forbid hipMalloc once they run.  Same
+ * arguments, same bytes.  The packed image is staged in a fixed device array that every GPU
+ * holds from library load to process exit (24.9 MB), so the film may have at most
+ * RT_NOALLOC_MAX_PIXELS pixels (3840 x 2160); a larger film is refused with an error.  The
+ * library itself makes no hipMalloc / hipFree or other allocating call here; the copy to `rgb8`
+ * is a device-to-host hipMemcpyAsync, so pass pinned memory (hipHostMalloc) if the HIP runtime
+ * must not stage or pin anything on its own either.  Like rt_film_quantize it blocks until the
+ * bytes have arrived (a stream synchronise): it cannot be called while the handle's stream is
+ * being captured into a HIP graph.  All handles of one GPU share the array; calls on one GPU are
+ * serialised by a per-GPU lock inside the library, and the array keeps the last call's bytes
  * (every word the copy reads is overwritten first, so nothing needs clearing). */
 #define RT_NOALLOC_MAX_PIXELS 8294400u
 int rt_film_quantize_noalloc(rt_handle *h, uint8_t *rgb8, double scale, uint32_t gamma);
 int rt_get_stats(rt_handle *h, rt_stats *out);
+
+/* ------------------------------------------------------------------ several GPUs: the film reduce
+ * Camera::render (camera.rs:368) sums `sqrt_spp^2` strata per pixel (camera.rs:390-395); the strata
+ * are independent, so each GPU renders the full frame for its own stratum range (rt_render_params)
+ * and the films -- fp32 SUMS -- are added once: an RCCL all-reduce (sum, fp32, width*height*3 values)
+ * enqueued on each handle's stream, behind that handle's render.  The reference has no counterpart
+ * (it is one thread).  librccl.so.1 is loaded when the first of these calls is made, not before.
+ *
+ * Two ways to form the group:
+ *   one process, one handle per GPU:   rt_comm_init_all(handles, n)      (ncclCommInitAll)
+ *   one process per GPU (n ranks):     rank 0 calls rt_comm_unique_id(id) and hands the
+ *       RT_COMM_ID_BYTES bytes to its peers by any means; every rank then calls
+ *       rt_comm_init_rank(h, id, rank, n)                                 (ncclCommInitRank)
+ * A handle belongs to at most one group; rt_comm_destroy (or rt_destroy) leaves it.
+ *
+ * rt_film_allreduce(handles, n): every film becomes the sum of all films of the group.  `handles`
+ * are this process's members of the group -- all n of them after rt_comm_init_all, the one local
+ * handle (n = 1) after rt_comm_init_rank; the films must have equal dimensions.  Asynchronous:
+ * the sums are complete once each handle's stream has passed the call (rt_synchronize, or any
+ * later call on the handle that reads the film).  A group of one rank returns the film unchanged. */
+#define RT_COMM_ID_BYTES 128u
+int rt_comm_init_all(rt_handle *const *handles, int n);
+int rt_comm_unique_id(void *id /* RT_COMM_ID_BYTES */, char *err, uint32_t err_len);
+int rt_comm_init_rank(rt_handle *h, const void *id /* RT_COMM_ID_BYTES */, int rank, int n_ranks);
+int rt_comm_destroy(rt_handle *h);
+/* rank of the handle in its group and the group's size; both 0 when it is in none */
+int rt_comm_info(rt_handle *h, int *rank, int *n_ranks);
+int rt_film_allreduce(rt_handle *const *handles, int n);
 
 /* Parity hook: closest hit of the uploaded world for n host rays (o,d: n*3; time: n or NULL).
  * origin_prim (n or NULL): id of the primitive each ray starts on, -1 for none -- what the

@@ -936,7 +936,12 @@ struct Renderer {
         c.bounce = cam.max_depth - depth;
         c.cnt[0]++;
         if (dead) c.cnt[8]++;
+        // Intersection-test counters (cnt[1..5]) cover the segments that carry weight: the ones the device
+        // traces too, so work per segment is averaged over one population (segments - zero-weight segments).
+        uint64_t keep[5];
+        if (dead) std::copy(c.cnt + 1, c.cnt + 6, keep);
         auto hit = world->hit(ray, Interval{0.001, INF}, c);
+        if (dead) std::copy(keep, keep + 5, c.cnt + 1);
         if (!hit) return cam.sky ? Camera::skybox(ray) : cam.bg;
         const Material *m = hit->material;
         Color emission = m->emitted(ray, *hit, hit->u, hit->v, hit->point);

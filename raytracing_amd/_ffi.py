@@ -63,13 +63,26 @@ class RtCamera(C.Structure):
                 ("defocus_disk_u", f64 * 3), ("defocus_disk_v", f64 * 3)]
 
 
-class RtRenderParams(C.Structure):
-    _fields_ = [("mode", u32), ("flags", u32), ("seed", u64), ("stratum_begin", u32), ("stratum_end", u32),
+RT_ABI_VERSION = 3  # of include/rt_amd.h as this file mirrors it; checked against the library at load
+
+
+class _Sized(C.Structure):
+    """A struct of rt_amd.h that starts with struct_size: set to this binding's size on creation."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(self)
+
+
+class RtRenderParams(_Sized):
+    _fields_ = [("struct_size", u32), ("mode", u32), ("flags", u32), ("reserved", u32), ("seed", u64),
+                ("stratum_begin", u32), ("stratum_end", u32),
                 ("pool_size", u32), ("time_every", u32), ("refill_min", u32), ("waves_per_simd", u32)]
 
 
-class RtStats(C.Structure):
-    _fields_ = [("segments", u64), ("camera_rays", u64), ("dropped", u64), ("iterations", u64),
+class RtStats(_Sized):
+    _fields_ = [("struct_size", u32), ("reserved", u32),
+                ("segments", u64), ("camera_rays", u64), ("dropped", u64), ("iterations", u64),
                 ("launches", u64 * 5), ("timed_launches", u64 * 5), ("kernel_ms", f64 * 5), ("render_ms", f64),
                 ("regrouped", u64)]
 
@@ -84,8 +97,8 @@ class CameraBuilderStruct(C.Structure):
 RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
 
 
-class RtAccelInfo(C.Structure):
-    _fields_ = [("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32), ("cost", f64),
+class RtAccelInfo(_Sized):
+    _fields_ = [("struct_size", u32), ("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32), ("cost", f64),
                 ("flat_quads", u32), ("flat_boxes", u32), ("flat_alone_spheres", u32), ("node_bytes", u32),
                 ("flat_boxes_aligned", u32), ("flat_boxes_upright", u32), ("flat_rects", u32)]
 
@@ -97,12 +110,14 @@ RT_FLAG_WAVEFRONT = 2
 RT_FLAG_REGROUP = 4
 RT_FLAG_NO_REGROUP = 8
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
+RT_COMM_ID_BYTES = 128
 RT_NODE_LEAF = 0xFFFFFFFF
 
 # name -> (restype, argtypes); every symbol include/rt_amd.h declares
 _vp = C.c_void_p
 _d3 = P(f64)
 SIGNATURES = {
+    "rt_abi_version": (u32, []),
     "rt_device_count": (C.c_int, [P(C.c_int)]),
     "rt_create": (C.c_int, [C.c_int, P(_vp)]),
     "rt_destroy": (None, [_vp]),
@@ -123,6 +138,12 @@ SIGNATURES = {
     "rt_film_quantize": (C.c_int, [_vp, P(C.c_uint8), f64, u32]),
     "rt_film_quantize_noalloc": (C.c_int, [_vp, P(C.c_uint8), f64, u32]),
     "rt_get_stats": (C.c_int, [_vp, P(RtStats)]),
+    "rt_comm_init_all": (C.c_int, [P(_vp), C.c_int]),
+    "rt_comm_unique_id": (C.c_int, [_vp, C.c_char_p, u32]),
+    "rt_comm_init_rank": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "rt_comm_destroy": (C.c_int, [_vp]),
+    "rt_comm_info": (C.c_int, [_vp, P(C.c_int), P(C.c_int)]),
+    "rt_film_allreduce": (C.c_int, [P(_vp), C.c_int]),
     "rt_intersect_batch": (C.c_int, [_vp, u32, P(f32), P(f32), P(f32), P(i32), f32, f32, P(i32), P(i32), P(f32), P(f32), P(f32)]),
     "rt_camera_rays": (C.c_int, [_vp, P(RtCamera), P(RtRenderParams), u32, P(u32), P(u32), P(f32), P(f32), P(f32)]),
     "rt_eval_texture": (C.c_int, [_vp, u32, u32, P(f32), P(f32)]),
@@ -187,6 +208,9 @@ def load_library(path=None):
         fn = getattr(lib, name)  # AttributeError here means the build is stale
         fn.restype = res
         fn.argtypes = args
+    have = lib.rt_abi_version()
+    if have != RT_ABI_VERSION:
+        raise ImportError(f"{path} speaks ABI {have}, this binding ABI {RT_ABI_VERSION}: rebuild the library (`make`)")
     return lib
 
 

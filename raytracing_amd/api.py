@@ -345,7 +345,9 @@ class Device:
         3840 x 2160) and makes no allocating call; `out` receives the bytes if given."""
         if out is None:
             out = np.empty((self.height, self.width, 3), dtype=np.uint8)
-        assert out.dtype == np.uint8 and out.flags.c_contiguous and out.size == self.height * self.width * 3
+        if not (isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous and out.flags.writeable
+                and out.size == self.height * self.width * 3):
+            raise ValueError(f"out must be a writable C-contiguous uint8 array of {self.height * self.width * 3} bytes")
         fn, name = (self.lib.rt_film_quantize_noalloc, "rt_film_quantize_noalloc") if no_alloc else \
             (self.lib.rt_film_quantize, "rt_film_quantize")
         self._check(fn(self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_double(scale), 1 if gamma else 0), name)
@@ -367,6 +369,29 @@ class Device:
 
     def synchronize(self):
         self._check(self.lib.rt_synchronize(self.h), "rt_synchronize")
+
+    # the film reduce of a multi-GPU render through the C ABI (RCCL inside the library)
+    def comm_init_rank(self, unique_id: bytes, rank, n_ranks):
+        """Joins the group named by `unique_id` (comm_unique_id() of rank 0) as `rank` of `n_ranks`:
+        one process per GPU."""
+        if len(unique_id) != _ffi.RT_COMM_ID_BYTES:
+            raise ValueError(f"the id has {_ffi.RT_COMM_ID_BYTES} bytes")
+        buf = C.create_string_buffer(bytes(unique_id), _ffi.RT_COMM_ID_BYTES)
+        self._check(self.lib.rt_comm_init_rank(self.h, C.cast(buf, C.c_void_p), rank, n_ranks), "rt_comm_init_rank")
+
+    def comm_destroy(self):
+        self._check(self.lib.rt_comm_destroy(self.h), "rt_comm_destroy")
+
+    def comm_info(self):
+        r, n = C.c_int(), C.c_int()
+        self._check(self.lib.rt_comm_info(self.h, C.byref(r), C.byref(n)), "rt_comm_info")
+        return r.value, n.value
+
+    def film_allreduce(self):
+        """Sum of the films of the group this handle joined with comm_init_rank, in place, enqueued on
+        the handle's stream."""
+        arr = (C.c_void_p * 1)(self.h)
+        self._check(self.lib.rt_film_allreduce(arr, 1), "rt_film_allreduce")
 
     def intersect_batch(self, o, d, time=None, tmin=0.001, tmax=float("inf"), origin_prim=None):
         o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
@@ -424,6 +449,29 @@ class Device:
         self._check(self.lib.rt_philox(self.h, ctr.shape[0], ctr.ctypes.data_as(up), key.ctypes.data_as(up),
                                        out.ctypes.data_as(up)), "rt_philox")
         return out
+
+
+def comm_unique_id() -> bytes:
+    """The id rank 0 hands to its peers for Device.comm_init_rank (ncclGetUniqueId inside the library)."""
+    buf = C.create_string_buffer(_ffi.RT_COMM_ID_BYTES)
+    err = C.create_string_buffer(1024)
+    if _ffi.lib.rt_comm_unique_id(C.cast(buf, C.c_void_p), err, 1024) < 0:
+        raise RtError(err.value.decode())
+    return buf.raw
+
+
+def comm_init_all(devices):
+    """One process driving several GPUs: forms one group of the given Devices (ncclCommInitAll)."""
+    arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    if _ffi.lib.rt_comm_init_all(arr, len(devices)) < 0:
+        raise RtError("rt_comm_init_all: " + _ffi.lib.rt_last_error(devices[0].h).decode())
+
+
+def film_allreduce_all(devices):
+    """The grouped all-reduce for the Devices of one comm_init_all group."""
+    arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    if _ffi.lib.rt_film_allreduce(arr, len(devices)) < 0:
+        raise RtError("rt_film_allreduce: " + _ffi.lib.rt_last_error(devices[0].h).decode())
 
 
 def device_count():

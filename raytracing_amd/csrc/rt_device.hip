@@ -4,9 +4,13 @@
 #include "rt_accel.h"
 #include "rt_flat.h"
 
+#include <rccl/rccl.h> // types only: the library is loaded when a group is formed (rt_comm_*)
+
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -76,6 +80,11 @@ struct rt_handle {
     // this device's copy of `scratch` (below): rt_film_quantize_noalloc
     uint32_t *noalloc_scratch = nullptr;
 
+    // the group this handle reduces its film with (rt_comm_*): an RCCL communicator
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
+    unsigned long long comm_group = 0; // which rt_comm_init_all made it (0: rt_comm_init_rank)
+
     // stats
     rt_stats stats{};
     std::vector<EventPair> ev_pool;
@@ -106,10 +115,42 @@ int fail(rt_handle *h, const std::string &msg) {
             return fail(h, std::string(#call) + ": " + hipGetErrorString(e_));               \
     } while (0)
 
+// rt_render_params as the caller's header defines it -> as this library does.  Fields are only ever
+// appended: a shorter struct comes from an older header and the fields it lacks are 0 (the defaults);
+// a longer one holds fields this library cannot honour and is refused.
+int read_params(rt_handle *h, const rt_render_params *in, rt_render_params *out) {
+    if (!in) return fail(h, "null render params");
+    constexpr uint32_t oldest = uint32_t(offsetof(rt_render_params, seed) + sizeof(uint64_t));
+    if (in->struct_size < oldest)
+        return fail(h, "rt_render_params.struct_size is " + std::to_string(in->struct_size) + ": set it to sizeof(rt_render_params) (header ABI " +
+                           std::to_string(RT_ABI_VERSION) + "; a binding built against an older header must be rebuilt)");
+    if (in->struct_size > sizeof(rt_render_params))
+        return fail(h, "rt_render_params comes from a newer header (" + std::to_string(in->struct_size) + " bytes) than this library (" +
+                           std::to_string(sizeof(rt_render_params)) + " bytes, ABI " + std::to_string(RT_ABI_VERSION) + ")");
+    *out = rt_render_params{};
+    std::memcpy(out, in, in->struct_size);
+    out->struct_size = uint32_t(sizeof(rt_render_params));
+    return 0;
+}
+// An output struct that starts with struct_size: the caller says how many bytes it has room for,
+// the library fills the part both know and says how many it filled.  Returns "" or what is wrong.
+template <typename T> std::string write_sized(const T &full, T *out, const char *name) {
+    const uint32_t room = out->struct_size;
+    if (room < 2 * sizeof(uint32_t))
+        return std::string(name) + ".struct_size is " + std::to_string(room) + ": set it to sizeof(" + name + ") before the call (header ABI " +
+               std::to_string(RT_ABI_VERSION) + ")";
+    T tmp = full;
+    tmp.struct_size = uint32_t(std::min<size_t>(room, sizeof(T)));
+    std::memcpy(out, &tmp, tmp.struct_size);
+    return "";
+}
+
 // The address of `scratch` on a device, looked up once per device with that device current.
 constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mutex;
 uint32_t *g_scratch_ptr[MAX_DEVICES] = {};
+// all handles of a device stage through that device's one array: one call at a time per device
+std::mutex g_scratch_in_use[MAX_DEVICES];
 int scratch_for_device(rt_handle *h, int device, uint32_t **out) {
     if (device < 0 || device >= MAX_DEVICES) return fail(h, "device id beyond the scratch table");
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -555,6 +596,61 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     return 0;
 }
 
+// ------------------------------------------------------------------ RCCL, loaded on first use
+// The film reduce is the only collective of the path.  librccl.so.1 (570 MB) is opened when a group
+// is formed, so a single-GPU user never loads it; in a process that already holds it (PyTorch) the
+// same soname resolves to that instance.
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+const Rccl *rccl(std::string &err) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return &g_rccl;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+        const char *why = dlerror();
+        err = std::string("cannot load librccl.so.1: ") + (why ? why : "unknown reason");
+        return nullptr;
+    }
+    Rccl r;
+    bool ok = true;
+    auto sym = [&](const char *name, auto &fn) {
+        fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(lib, name));
+        if (!fn) ok = false, err = std::string("librccl.so.1 has no ") + name;
+    };
+    sym("ncclGetUniqueId", r.GetUniqueId);
+    sym("ncclCommInitRank", r.CommInitRank);
+    sym("ncclCommInitAll", r.CommInitAll);
+    sym("ncclCommDestroy", r.CommDestroy);
+    sym("ncclAllReduce", r.AllReduce);
+    sym("ncclGroupStart", r.GroupStart);
+    sym("ncclGroupEnd", r.GroupEnd);
+    sym("ncclGetErrorString", r.GetErrorString);
+    if (!ok) {
+        dlclose(lib);
+        return nullptr;
+    }
+    r.lib = lib;
+    g_rccl = r;
+    return &g_rccl;
+}
+std::string rccl_what(const Rccl *r, const char *call, ncclResult_t rc) {
+    return std::string(call) + ": " + r->GetErrorString(rc);
+}
+// groups formed by rt_comm_init_all get a number, so that rt_film_allreduce can tell that the
+// handles it is given are the members of ONE group; 0 = a group of one handle per process
+unsigned long long g_next_group = 1;
+
 } // namespace
 
 extern "C" {
@@ -567,6 +663,8 @@ int rt_debug_regroup_stats(unsigned long long *out) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_rg_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
 
 int rt_device_count(int *n) {
     rt_handle *h = nullptr;
@@ -619,6 +717,7 @@ void rt_destroy(rt_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) (void)rt_comm_destroy(h);
     free_scene(h);
     free_queue(h);
     if (h->film && h->film_owned) (void)hipFree(h->film);
@@ -883,19 +982,22 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
     if (e.empty()) e = accel::verify_wide_bvh(scene, nodes);
     if (!e.empty()) return say("rt_accel_selftest: " + e);
     if (out) {
-        out->kind = uint32_t(ACCEL_BVH4);
-        out->nodes = st.nodes, out->depth = st.depth, out->stack_entries = st.stack_need, out->cost = st.cost;
+        rt_accel_info a{};
+        a.kind = uint32_t(ACCEL_BVH4);
+        a.nodes = st.nodes, a.depth = st.depth, a.stack_entries = st.stack_need, a.cost = st.cost;
         // what the upload would make of the scene as a flat world (0s unless it is one list of primitives)
         flat::Plan fp;
         e = flat::plan(scene, fp);
         if (!e.empty()) return say("rt_accel_selftest: " + e);
-        out->flat_quads = fp.n_quads, out->flat_boxes = uint32_t(fp.boxes.size() / 32), out->flat_alone_spheres = uint32_t(fp.alone_spheres.size());
-        out->flat_boxes_aligned = fp.n_boxes_aligned, out->flat_boxes_upright = fp.n_boxes_upright;
-        out->flat_rects = uint32_t(fp.rects.size() / 8);
-        out->node_bytes = uint32_t(sizeof(Node4Q));
+        a.flat_quads = fp.n_quads, a.flat_boxes = uint32_t(fp.boxes.size() / 32), a.flat_alone_spheres = uint32_t(fp.alone_spheres.size());
+        a.flat_boxes_aligned = fp.n_boxes_aligned, a.flat_boxes_upright = fp.n_boxes_upright;
+        a.flat_rects = uint32_t(fp.rects.size() / 8);
+        a.node_bytes = uint32_t(sizeof(Node4Q));
         std::vector<Node4Q> q;
         accel::quantise_nodes(nodes, q);
         e = accel::verify_quantised(nodes, q);
+        if (!e.empty()) return say("rt_accel_selftest: " + e);
+        e = write_sized(a, out, "rt_accel_info");
         if (!e.empty()) return say("rt_accel_selftest: " + e);
     }
     return 0;
@@ -905,19 +1007,21 @@ int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     if (!h || !out) return -1;
     if (!h->have_scene) return fail(h, "rt_get_accel_info: no scene uploaded");
     const bool wide = accel_is_wide(h->accel);
-    out->kind = wide ? uint32_t(ACCEL_BVH4) : uint32_t(h->accel);
-    out->nodes = wide ? h->accel_stats.nodes : (h->accel == ACCEL_BVH2 ? h->sc.n_nodes : 0u);
-    out->depth = wide ? h->accel_stats.depth : 0u;
-    out->stack_entries = wide ? h->stack4 : (h->accel == ACCEL_BVH2 ? uint32_t(STACK_DEPTH) : 0u);
-    out->cost = wide ? h->accel_stats.cost : 0.0;
-    out->node_bytes = wide ? uint32_t(h->node4_bytes()) : (h->accel == ACCEL_BVH2 ? uint32_t(sizeof(rt_node)) : 0u);
-    out->flat_quads = h->accel == ACCEL_FLAT ? h->sc.n_flat_quads : 0u;
-    out->flat_boxes = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes : 0u;
-    out->flat_alone_spheres = h->alone_spheres;
-    out->flat_boxes_aligned = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_aligned : 0u;
-    out->flat_boxes_upright = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_upright : 0u;
-    out->flat_rects = h->accel == ACCEL_FLAT ? h->sc.n_flat_rects : 0u;
-    return 0;
+    rt_accel_info a{};
+    a.kind = wide ? uint32_t(ACCEL_BVH4) : uint32_t(h->accel);
+    a.nodes = wide ? h->accel_stats.nodes : (h->accel == ACCEL_BVH2 ? h->sc.n_nodes : 0u);
+    a.depth = wide ? h->accel_stats.depth : 0u;
+    a.stack_entries = wide ? h->stack4 : (h->accel == ACCEL_BVH2 ? uint32_t(STACK_DEPTH) : 0u);
+    a.cost = wide ? h->accel_stats.cost : 0.0;
+    a.node_bytes = wide ? uint32_t(h->node4_bytes()) : (h->accel == ACCEL_BVH2 ? uint32_t(sizeof(rt_node)) : 0u);
+    a.flat_quads = h->accel == ACCEL_FLAT ? h->sc.n_flat_quads : 0u;
+    a.flat_boxes = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes : 0u;
+    a.flat_alone_spheres = h->alone_spheres;
+    a.flat_boxes_aligned = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_aligned : 0u;
+    a.flat_boxes_upright = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_upright : 0u;
+    a.flat_rects = h->accel == ACCEL_FLAT ? h->sc.n_flat_rects : 0u;
+    const std::string bad = write_sized(a, out, "rt_accel_info");
+    return bad.empty() ? 0 : fail(h, "rt_get_accel_info: " + bad);
 }
 
 int rt_film_clear(rt_handle *h) {
@@ -1038,18 +1142,150 @@ int rt_film_quantize_noalloc(rt_handle *h, uint8_t *rgb8, double scale, uint32_t
         return fail(h, "rt_film_quantize_noalloc: film of " + std::to_string(uint64_t(h->film_w) * h->film_h) +
                            " pixels exceeds the fixed scratch of " + std::to_string(NOALLOC_MAX_PIXELS) +
                            " pixels (3840 x 2160); use rt_film_quantize");
-    // the kernel overwrites every word of the scratch that the copy reads: nothing to clear
+    // the kernel overwrites every word of the scratch that the copy reads: nothing to clear.  The lock
+    // covers the launch, the copy and the stream synchronise (quantize_into returns when the bytes are home).
+    std::lock_guard<std::mutex> lock(g_scratch_in_use[h->device]);
     return quantize_into(h, "rt_film_quantize_noalloc", h->noalloc_scratch, rgb8, scale, gamma);
+}
+
+int rt_comm_init_all(rt_handle *const *handles, int n) {
+    if (!handles || n < 1 || !handles[0]) return -1;
+    rt_handle *h = handles[0];
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return fail(h, "rt_comm_init_all: null handle in the list");
+        if (handles[i]->comm) return fail(h, "rt_comm_init_all: handle " + std::to_string(i) + " already belongs to a group (rt_comm_destroy first)");
+        for (int d : devs)
+            if (d == handles[i]->device) return fail(h, "rt_comm_init_all: two handles on GPU " + std::to_string(d) + " (RCCL takes one rank per GPU)");
+        devs.push_back(handles[i]->device);
+    }
+    std::string err;
+    const Rccl *r = rccl(err);
+    if (!r) return fail(h, "rt_comm_init_all: " + err);
+    std::vector<ncclComm_t> comms(n, nullptr);
+    const ncclResult_t rc = r->CommInitAll(comms.data(), n, devs.data());
+    if (rc != ncclSuccess) return fail(h, "rt_comm_init_all: " + rccl_what(r, "ncclCommInitAll", rc));
+    unsigned long long group;
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        group = g_next_group++;
+    }
+    for (int i = 0; i < n; ++i) handles[i]->comm = comms[i], handles[i]->comm_rank = i, handles[i]->comm_size = n, handles[i]->comm_group = group;
+    return 0;
+}
+
+int rt_comm_unique_id(void *id, char *err, uint32_t err_len) {
+    auto say = [&](const std::string &m) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", m.c_str());
+        return -1;
+    };
+    static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "the id is handed over as RT_COMM_ID_BYTES opaque bytes");
+    if (!id) return say("rt_comm_unique_id: null argument");
+    std::string e;
+    const Rccl *r = rccl(e);
+    if (!r) return say("rt_comm_unique_id: " + e);
+    ncclUniqueId uid;
+    const ncclResult_t rc = r->GetUniqueId(&uid);
+    if (rc != ncclSuccess) return say("rt_comm_unique_id: " + rccl_what(r, "ncclGetUniqueId", rc));
+    std::memcpy(id, &uid, sizeof(uid));
+    return 0;
+}
+
+int rt_comm_init_rank(rt_handle *h, const void *id, int rank, int n_ranks) {
+    if (!h) return -1;
+    if (!id) return fail(h, "rt_comm_init_rank: null id");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, "rt_comm_init_rank: rank outside 0..n_ranks");
+    if (h->comm) return fail(h, "rt_comm_init_rank: the handle already belongs to a group (rt_comm_destroy first)");
+    std::string err;
+    const Rccl *r = rccl(err);
+    if (!r) return fail(h, "rt_comm_init_rank: " + err);
+    RT_HIP(hipSetDevice(h->device)); // the communicator binds to the current device
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = r->CommInitRank(&comm, n_ranks, uid, rank);
+    if (rc != ncclSuccess) return fail(h, "rt_comm_init_rank: " + rccl_what(r, "ncclCommInitRank", rc));
+    h->comm = comm, h->comm_rank = rank, h->comm_size = n_ranks, h->comm_group = 0;
+    return 0;
+}
+
+int rt_comm_destroy(rt_handle *h) {
+    if (!h) return -1;
+    if (!h->comm) return 0;
+    std::string err;
+    const Rccl *r = rccl(err);
+    if (!r) return fail(h, "rt_comm_destroy: " + err);
+    RT_HIP(hipSetDevice(h->device));
+    RT_HIP(hipStreamSynchronize(h->stream)); // a reduce in flight still uses the communicator
+    const ncclResult_t rc = r->CommDestroy(h->comm);
+    h->comm = nullptr, h->comm_rank = h->comm_size = 0, h->comm_group = 0;
+    if (rc != ncclSuccess) return fail(h, "rt_comm_destroy: " + rccl_what(r, "ncclCommDestroy", rc));
+    return 0;
+}
+
+int rt_comm_info(rt_handle *h, int *rank, int *n_ranks) {
+    if (!h || !rank || !n_ranks) return -1;
+    *rank = h->comm ? h->comm_rank : 0;
+    *n_ranks = h->comm ? h->comm_size : 0;
+    return 0;
+}
+
+int rt_film_allreduce(rt_handle *const *handles, int n) {
+    if (!handles || n < 1 || !handles[0]) return -1;
+    rt_handle *h = handles[0];
+    for (int i = 0; i < n; ++i) {
+        rt_handle *m = handles[i];
+        if (!m) return fail(h, "rt_film_allreduce: null handle in the list");
+        if (!m->comm) return fail(h, "rt_film_allreduce: handle " + std::to_string(i) + " is in no group (rt_comm_init_all / rt_comm_init_rank)");
+        if (!m->film) return fail(h, "rt_film_allreduce: handle " + std::to_string(i) + " has no film");
+        if (m->film_w != h->film_w || m->film_h != h->film_h) return fail(h, "rt_film_allreduce: the films differ in size");
+        if (m->comm_group != h->comm_group) return fail(h, "rt_film_allreduce: the handles belong to different groups");
+        for (int k = 0; k < i; ++k)
+            if (handles[k] == m) return fail(h, "rt_film_allreduce: a handle is listed twice");
+    }
+    // every member this process holds must take part in the one grouped call, or the others wait forever
+    const int local_members = h->comm_group ? h->comm_size : 1;
+    if (n != local_members)
+        return fail(h, "rt_film_allreduce: " + std::to_string(n) + " handles given, this process holds " + std::to_string(local_members) + " member(s) of the group");
+    std::string err;
+    const Rccl *r = rccl(err);
+    if (!r) return fail(h, "rt_film_allreduce: " + err);
+    const size_t count = size_t(h->film_w) * h->film_h * 3;
+    ncclResult_t rc = r->GroupStart();
+    if (rc != ncclSuccess) return fail(h, "rt_film_allreduce: " + rccl_what(r, "ncclGroupStart", rc));
+    ncclResult_t first_bad = ncclSuccess;
+    for (int i = 0; i < n; ++i) {
+        rt_handle *m = handles[i];
+        if (hipSetDevice(m->device) != hipSuccess) {
+            first_bad = ncclUnhandledCudaError;
+            break;
+        }
+        // in place, on the handle's stream: ordered behind the render that filled the film
+        rc = r->AllReduce(m->film, m->film, count, ncclFloat32, ncclSum, m->comm, m->stream);
+        if (rc != ncclSuccess) {
+            first_bad = rc;
+            break;
+        }
+    }
+    rc = r->GroupEnd(); // always closed, or the thread stays inside a group
+    if (first_bad != ncclSuccess) return fail(h, "rt_film_allreduce: " + rccl_what(r, "ncclAllReduce", first_bad));
+    if (rc != ncclSuccess) return fail(h, "rt_film_allreduce: " + rccl_what(r, "ncclGroupEnd", rc));
+    return 0;
 }
 
 int rt_get_stats(rt_handle *h, rt_stats *out) {
     if (!h || !out) return -1;
-    *out = h->stats;
-    return 0;
+    const std::string bad = write_sized(h->stats, out, "rt_stats");
+    return bad.empty() ? 0 : fail(h, "rt_get_stats: " + bad);
 }
 
-int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *p) {
+int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *params) {
     if (!h) return -1;
+    rt_render_params own;
+    if (read_params(h, params, &own)) return -1;
+    const rt_render_params *p = &own;
+    if ((p->flags & RT_FLAG_REGROUP) && (p->flags & RT_FLAG_NO_REGROUP))
+        return fail(h, "rt_render: RT_FLAG_REGROUP and RT_FLAG_NO_REGROUP are both set");
     RT_HIP(hipSetDevice(h->device));
     if (!h->have_scene) return fail(h, "rt_render: no scene uploaded");
     DCamera dc;
@@ -1230,9 +1466,12 @@ int rt_intersect_batch(rt_handle *h, uint32_t n, const float *o, const float *d,
     return 0;
 }
 
-int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *p, uint32_t n, const uint32_t *pixel,
+int rt_camera_rays(rt_handle *h, const rt_camera *cam, const rt_render_params *params, uint32_t n, const uint32_t *pixel,
                    const uint32_t *stratum, float *o, float *d, float *time) {
     if (!h) return -1;
+    rt_render_params own;
+    if (read_params(h, params, &own)) return -1;
+    const rt_render_params *p = &own;
     RT_HIP(hipSetDevice(h->device));
     DCamera dc;
     uint32_t se;

@@ -46,11 +46,13 @@ std::vector<Color> Camera::render(const Hittable &world, const Hittable *lights,
     check(dev.h, rt_upload_scene(dev.h, &flat->desc), "rt_upload_scene");
     check(dev.h, rt_film_resize(dev.h, derived.image_width, derived.image_height), "rt_film_resize");
     rt_render_params p{};
+    p.struct_size = sizeof(p);
     p.mode = settings.mode;
     p.flags = settings.flags;
     p.seed = settings.seed;
     check(dev.h, rt_render(dev.h, &derived, &p), "rt_render"); // all sqrt_spp^2 strata
     rt_stats st{};
+    st.struct_size = sizeof(st);
     check(dev.h, rt_get_stats(dev.h, &st), "rt_get_stats");
     if (report) report->segments = st.segments, report->camera_rays = st.camera_rays, report->dropped = st.dropped, report->render_ms = st.render_ms;
     const size_t n = size_t(derived.image_width) * derived.image_height;

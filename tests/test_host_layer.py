@@ -20,11 +20,46 @@ lib = _ffi.lib
 
 def test_library_exports_every_declared_symbol():
     header = (ROOT / "include" / "rt_amd.h").read_text()
-    declared = set(re.findall(r"^(?:int|void|double|const char \*|rth_scene \*)\s*\*?(rth?_[a-z0-9_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|double|uint32_t|const char \*|rth_scene \*)\s*\*?(rth?_[a-z0-9_]+)\s*\(", header, re.M))
     assert len(declared) > 55
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in rt_amd.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+
+
+def test_abi_handshake():
+    """A binding built against another header fails loudly instead of reading past its struct."""
+    header = (ROOT / "include" / "rt_amd.h").read_text()
+    assert lib.rt_abi_version() == int(re.search(r"#define RT_ABI_VERSION (\d+)u", header).group(1)) == _ffi.RT_ABI_VERSION
+    # every struct that carries struct_size sets it on creation in this binding
+    for cls in (_ffi.RtRenderParams, _ffi.RtStats, _ffi.RtAccelInfo):
+        assert cls().struct_size == C.sizeof(cls) and cls._fields_[0][0] == "struct_size"
+    sb = ra.SceneBuilder()
+    ra.scenes.cornell_main(sb)
+    desc = sb.flatten()
+    err = C.create_string_buffer(512)
+    # an output struct: struct_size 0 (a binding from before the field existed) is refused, nothing written
+    info = _ffi.RtAccelInfo()
+    info.struct_size = 0
+    info.nodes = 12345
+    assert lib.rt_accel_selftest(desc, _ffi.RT_BUILD_AUTO, C.byref(info), err, 512) < 0
+    assert b"struct_size" in err.value and info.nodes == 12345
+    # a shorter struct (an older header): only that many bytes are written, and the library says so
+    class Padded(C.Structure):
+        _fields_ = [("info", _ffi.RtAccelInfo), ("guard", C.c_uint32 * 4)]
+    pad = Padded()
+    for i in range(4):
+        pad.guard[i] = 0xDEADBEEF
+    short = _ffi.RtAccelInfo.flat_rects.offset  # without the last field
+    pad.info.struct_size = short
+    pad.info.flat_rects = 0xABCD
+    assert lib.rt_accel_selftest(desc, _ffi.RT_BUILD_AUTO, C.byref(pad.info), err, 512) == 0, err.value
+    assert pad.info.struct_size == short and pad.info.flat_rects == 0xABCD and pad.info.flat_boxes == 3
+    # a longer struct (a newer header): the library fills what it knows and reports its own size
+    pad.info.struct_size = C.sizeof(Padded)
+    assert lib.rt_accel_selftest(desc, _ffi.RT_BUILD_AUTO, C.byref(pad.info), err, 512) == 0, err.value
+    assert pad.info.struct_size == C.sizeof(_ffi.RtAccelInfo) and list(pad.guard) == [0xDEADBEEF] * 4
+    assert pad.info.flat_rects == 1
 
 
 def test_no_gpu_means_loud_failure():

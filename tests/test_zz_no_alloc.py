@@ -24,9 +24,31 @@ def _render(dev, width, spp, seed):
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_no_alloc_quantize_equals_the_allocating_entry_point_twice_in_a_row():
+    import torch
+    lib = _ffi.lib
+    u8p = C.POINTER(C.c_uint8)
+    # What the entry point exists for: on a handle that has never made an allocating film call, the
+    # first quantize through the fixed array leaves the device's free memory where it was (the
+    # destination is pinned, so the runtime has nothing to stage either).
+    fresh = ra.Device(0)
+    try:
+        cam = _render(fresh, 1024, 1, 2)  # 3 MB of packed bytes: an allocation of that size shows in the free memory
+        fresh.synchronize()
+        pinned = torch.empty(1024 * 1024 * 3, dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        assert lib.rt_film_quantize_noalloc(fresh.h, C.cast(pinned.data_ptr(), u8p), C.c_double(0.25), 0) == 0, \
+            lib.rt_last_error(fresh.h).decode()
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        got_first = pinned.numpy().copy()
+        free_mid = torch.cuda.mem_get_info(0)[0]
+        want_first = fresh.film_rgb8(0.25)  # the allocating entry point: takes its staging buffer now
+        assert torch.cuda.mem_get_info(0)[0] < free_mid
+        assert got_first.max() > 0 and np.array_equal(got_first, want_first.ravel())
+    finally:
+        fresh.close()
     dev = ra.Device(0)
     try:
-        lib = _ffi.lib
         for width, spp, seed in [(192, 9, 3), (80, 4, 4)]:  # the second film is smaller
             cam = _render(dev, width, spp, seed)
             npix = width * width
@@ -34,7 +56,6 @@ def test_no_alloc_quantize_equals_the_allocating_entry_point_twice_in_a_row():
                 scale = 1.0 / cam.effective_spp
                 want = np.zeros(npix * 3, np.uint8)
                 got = np.full(npix * 3 + 64, 0xA5, np.uint8)  # guard bytes behind the image
-                u8p = C.POINTER(C.c_uint8)
                 assert lib.rt_film_quantize(dev.h, want.ctypes.data_as(u8p), C.c_double(scale), gamma) == 0
                 assert lib.rt_film_quantize_noalloc(dev.h, got.ctypes.data_as(u8p), C.c_double(scale), gamma) == 0, \
                     lib.rt_last_error(dev.h).decode()
