@@ -57,14 +57,29 @@ FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path dep
 # algorithmic flops per segment measured by the oracle's counters (flops_per_segment below) on
 # the full workloads; used when the CPU leg is skipped, recomputed when it runs
 # (c2, c4, c5: full scene content, a few strata of the full frame, the reference's own binary BVH
-# walked left child first -- 40.9, 15.7 and 340.7 box tests per segment)
-FLOPS_PER_SEGMENT = {"c3": 548.3, "c1": 598.0, "c2": 1310.7, "c4": 1248.7, "c5": 9525.6}
-# HBM-side bytes per segment of the persistent kernel from rocprofv3 PMC passes (FETCH_SIZE x2 +
-# WRITE_SIZE, both in KiB, over two dispatches of the 64-spp frame = 861.4 M segments), keyed by
-# (workload, regrouping variant): profiles/r2_pmc_c3_spp64.txt and
-# profiles/r1g_pmc_c3_spp64_persistent.txt.  Not collected live: counters need their own runs.
-PMC_BYTES_PER_SEGMENT = {("c3", True): (2 * 552 + 4073822) * 1024 / 861.4e6,
-                         ("c3", False): (2 * 12796 + 4905618) * 1024 / 861.4e6}
+# walked left child first -- 40.9, 12.2 and 340.8 box tests per segment).  Averaged over the
+# segments that carry weight, the ones the device traces (see live_segments).
+FLOPS_PER_SEGMENT = {"c3": 499.4, "c1": 681.4, "c2": 1310.7, "c4": 934.4, "c5": 9528.7}
+# Counter digests of the dominant kernel per workload, made from rocprofv3 PMC passes of this
+# binary by tools/pmc_to_bench.py (counters need runs of their own: FETCH_SIZE and WRITE_SIZE do
+# not fit one pass).  Each entry names the summary under profiles/ it was made from.
+PMC_DIGEST = ROOT / "bench_pmc.json"
+
+
+def pmc_digest(workload, kernel):
+    """{"hbm_bytes_per_segment", "lanes_active", "valu_busy", "source"} for this workload's kernel, or None."""
+    try:
+        entry = json.loads(PMC_DIGEST.read_text()).get(workload)
+    except (OSError, ValueError):
+        return None
+    return entry if entry and entry.get("kernel", "").startswith(kernel) else None
+
+
+def live_segments(cnt):
+    """The oracle's segments that carry weight.  It traces a path whose weight has become exactly 0
+    to its end like the reference does and counts those segments apart; the device stops such a
+    path.  Rates and per-segment figures of both sides are over this population."""
+    return cnt["segments"] - cnt["zero_weight_segments"]
 
 
 def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads, shrink=1):
@@ -90,7 +105,7 @@ def cpu_baseline(scene_fn, kw, mode, n_strata_sample, threads, shrink=1):
 def flops_per_segment(cnt):
     """Algorithmic work of one segment from the oracle's counters: 24/box test, 30/sphere test,
     +30/sphere hit record, 13/quad plane test, +37/quad interior test, 150 for shading."""
-    s = max(cnt["segments"], 1)
+    s = max(live_segments(cnt), 1)  # the oracle counts the tests of these segments only
     return (24 * cnt["box_tests"] + 30 * cnt["sphere_tests"] + 30 * cnt["sphere_accepts"] + 13 * cnt["quad_plane_tests"] +
             37 * cnt["quad_interior_tests"]) / s + 150.0
 
@@ -250,13 +265,15 @@ def main():
         frame = "full frame" if shrink == 1 else f"frame at 1/{shrink} of the resolution per axis"
         cnt, dt, _ = cpu_baseline(scene_fn, kw, mode, cpu_strata, threads=1, shrink=shrink)
         fps = flops_per_segment(cnt)
-        out["cpu_baseline"] = {"value": round(cnt["segments"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
+        out["cpu_baseline"] = {"value": round(live_segments(cnt) / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
                                "sample": f"{frame}, {cpu_strata} of {n_strata} strata ({cnt['camera_rays']} camera rays, "
-                                         f"{cnt['segments']} segments, {dt:.1f} s); C++ f64 restatement of the reference, not the Rust binary"}
+                                         f"{live_segments(cnt)} segments that carry weight -- the population the device traces -- of "
+                                         f"{cnt['segments']} the reference's loop traces, {dt:.1f} s); C++ f64 restatement of the "
+                                         "reference, not the Rust binary"}
         nthreads = min(16, os.cpu_count() or 1)
         many = max(cpu_strata, 8) if args.workload in ("c3", "c1") else cpu_strata * 4
         cnt2, dt2, _ = cpu_baseline(scene_fn, kw, mode, min(many, n_strata), threads=nthreads, shrink=shrink)
-        out["cpu_baseline_all_cores"] = {"value": round(cnt2["segments"] / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": nthreads,
+        out["cpu_baseline_all_cores"] = {"value": round(live_segments(cnt2) / dt2 / 1e6, 3), "unit": "Mrays/s", "cores": nthreads,
                                          "kind": "port", "sample": f"{frame}, {min(many, n_strata)} strata, OpenMP rows, {dt2:.1f} s"}
         out["time_to_1000spp_cpu_1core_s"] = round(dt / cpu_strata * 1000.0 * shrink * shrink, 1)
     # The path has no dense contraction and moves almost nothing through HBM: its roofline is
@@ -270,11 +287,13 @@ def main():
             kernel_name = "k_scan+k_generate+k_extend+k_shade"
             all_ms = float(np.sum(per_launch_ms * launches))
             tflops = fps * seg / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0
+        pmc = pmc_digest(args.workload, kernel_name) if names[k] == "paths" else None
         out["roofline"] = {"bound": "valu", "kernel": kernel_name, "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 5),
-                           "traffic": (round(PMC_BYTES_PER_SEGMENT[(args.workload, regrouped)] * seg_per_launch)
-                                       if names[k] == "paths" and (args.workload, regrouped) in PMC_BYTES_PER_SEGMENT and not args.spp else None),
-                           "traffic_unit": "bytes per launch, HBM side, PMC bytes/segment x segments of this launch",
+                           "traffic": round(pmc["hbm_bytes_per_segment"] * seg_per_launch) if pmc else None,
+                           "traffic_unit": "bytes per launch, HBM side: (2 x FETCH_SIZE + WRITE_SIZE) per segment of the counter "
+                                           "passes x segments of this launch",
+                           **({"lanes_active": pmc["lanes_active"], "valu_busy": pmc["valu_busy"], "pmc_source": pmc["source"]} if pmc else {}),
                            "flops_per_segment": round(fps, 1), "segments_per_launch": int(seg_per_launch),
                            "avg_launch_ms": round(float(avg_launch_ms), 4), "launches": int(launches[k]),
                            "timed_launches": int(timed[k]),

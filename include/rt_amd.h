@@ -239,20 +239,30 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *scene);
  *   width 4 (default, with RT_BUILD_AUTO): binary nodes and lists collapsed into 4-wide nodes with boxes recomputed
  *           from the fp32 primitives; builder RT_BUILD_REFERENCE keeps the descriptor's
  *           grouping, RT_BUILD_SAH regroups all primitives by a binned surface-area heuristic,
- *           RT_BUILD_AUTO builds both and keeps the cheaper by surface-area cost;
+ *           RT_BUILD_AUTO builds both and keeps the one that is cheaper to walk (rt_accel_info.walk_cost);
  *   width 2: the descriptor's nodes traversed as they are (near child first).
  * A world that is one short list of primitives is scanned without any tree either way; boxes
  * at the end of its quads (main.rs:52-69) are recognised and tested as boxes, with the hit
  * reported on the face's own quad. */
 #define RT_BUILD_REFERENCE 0u
 #define RT_BUILD_SAH 1u
-#define RT_BUILD_AUTO 2u /* both, keep the lower surface-area cost */
+#define RT_BUILD_AUTO 2u /* both, keep the one that is cheaper to walk */
 /* Or-ed into the builder: the size of a 4-wide node.  128 bytes with fp32 child boxes, or 64 bytes
  * whose child boxes are bytes on a grid of the node's own, rounded outward -- the same tree and the
  * same hits, half the bytes and four loads instead of seven per visit, a little more arithmetic.
  * With neither flag the upload picks by the size of the tree (byte boxes from 8192 nodes). */
 #define RT_BUILD_FP32_BOXES 0x100u
 #define RT_BUILD_BYTE_BOXES 0x200u
+/* Or-ed into the builder: six parallelograms of one list that are the faces of a box along the
+ * world's axes (box3, hittable.rs:398-455) normally become ONE leaf of the 4-wide tree, searched
+ * with one slab test and reported on the face's own quad -- same hits, same primitive ids, a sixth
+ * of the leaves.  This flag keeps them six quads (for comparisons). */
+#define RT_BUILD_NO_BOX_LEAVES 0x400u
+/* Or-ed into the builder: a sphere or medium that encloses the rest of the scene (the fog of radius
+ * 5000 around "The Next Week"'s final scene) is normally kept out of the 4-wide tree and tested once
+ * per ray when the ray's walk through the tree has ended -- no box can cull it, and the closest hit
+ * does not depend on the order of the tests.  This flag leaves such primitives in the tree. */
+#define RT_BUILD_NO_POST_TESTS 0x800u
 int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width);
 typedef struct {
     uint32_t struct_size;   /* in: sizeof(rt_accel_info) of the caller's header; out: bytes the library filled */
@@ -273,6 +283,12 @@ typedef struct {
                              * do not need.  Both are 0 when the list orders its boxes otherwise. */
     uint32_t flat_rects;    /* flat only: rectangles along the world's axes (a lamp under a ceiling) that left
                              * flat_quads for a test without dot products; same hits, same tie order */
+    uint32_t box_leaves;    /* wide only: leaves that are a whole axis-aligned box (six quads each) */
+    uint32_t leaves;        /* wide only: leaves of the tree (a box leaf counts once) */
+    uint32_t post_tests;    /* wide only: primitives enclosing the scene, tested after the walk instead of in the tree */
+    uint32_t reserved;
+    double walk_cost;       /* wide only: measured work of walking a surface-to-surface segment through the tree, in
+                             * node visits; what RT_BUILD_AUTO compares */
 } rt_accel_info;
 int rt_get_accel_info(rt_handle *h, rt_accel_info *out);
 /* Host only (no device needed): builds the 4-wide structure for a descriptor and checks it

@@ -194,6 +194,9 @@ struct Ctx {
     int exclude_prim = -1;
     int error = 0; // 1: material not renderable in this mode (reference panics)
     uint64_t cnt[ORC_NCOUNTERS] = {0};
+    // orc_render_flagged: the path in flight has scattered off a sphere smaller than flag_radius
+    double flag_radius = 0;
+    bool path_flag = false;
 };
 
 // vec.rs:211-223
@@ -379,6 +382,7 @@ struct HitRecord { // hittable.rs:13-28
     double u = 0, v = 0, t = 0;
     bool front_face = false;
     int prim = -1;
+    double sphere_radius = 0; // > 0: the hit is on a sphere of that radius (orc_render_flagged only)
     // hittable.rs:59-79
     static HitRecord from_incoming_ray(const Ray &ray, V3 point, V3 normal, double t, double u, double v,
                                        const Material *m, int prim) {
@@ -571,7 +575,9 @@ struct Sphere : Hittable { // hittable.rs:117-209
         V3 normal = (point - center) / radius;
         double u, v;
         sphere_get_uv(normal, u, v);
-        return HitRecord::from_incoming_ray(ray, point, normal, root, u, v, mat, prim);
+        HitRecord rec = HitRecord::from_incoming_ray(ray, point, normal, root, u, v, mat, prim);
+        rec.sphere_radius = radius;
+        return rec;
     }
     const BBox *bounding_box() const override { return &bbox; }
     // Not in the reference (only Parallelogram overrides these).  "The Rest of Your Life" ch.12.
@@ -948,6 +954,7 @@ struct Renderer {
         c.rng.begin(STREAM_SHADE, c.bounce);
         auto sc = m->scatter(ray, *hit, c);
         if (!sc || c.error) return emission;
+        if (hit->sphere_radius > 0 && hit->sphere_radius < c.flag_radius) c.path_flag = true; // orc_render_flagged
         if (c.mode == ORC_MODE_BOOK3) return book3_tail(ray, *hit, *sc, emission, depth, dead);
 
         // shipped estimator: light-only sampling, BSDF pdf on the material's own sample
@@ -1201,8 +1208,24 @@ int orc_set_lights(orc_scene *s, int obj) {
 }
 int orc_prim_count(orc_scene *s) { return s->nprims; }
 
+namespace {
+int render_impl(orc_scene *s, const orc_camera *cb, const orc_render_params *p, double *film_sum, double *film_sumsq,
+                uint64_t *counters, double flag_radius, uint32_t *flagged);
+}
 int orc_render(orc_scene *s, const orc_camera *cb, const orc_render_params *p, double *film_sum,
                double *film_sumsq, uint64_t *counters) {
+    return render_impl(s, cb, p, film_sum, film_sumsq, counters, 0.0, nullptr);
+}
+int orc_render_flagged(orc_scene *s, const orc_camera *cb, const orc_render_params *p, double *film_sum, double radius_below,
+                       uint32_t *flagged) {
+    if (!flagged) return fail(s, "render_flagged: null output");
+    Camera cam(*cb);
+    std::memset(flagged, 0, sizeof(uint32_t) * size_t(cam.image_width) * cam.image_height);
+    return render_impl(s, cb, p, film_sum, nullptr, nullptr, radius_below, flagged);
+}
+namespace {
+int render_impl(orc_scene *s, const orc_camera *cb, const orc_render_params *p, double *film_sum, double *film_sumsq,
+                uint64_t *counters, double flag_radius, uint32_t *flagged) {
     if (!s->world) return fail(s, "render: no world set");
     Camera cam(*cb);
     if (cam.sqrt_spp == 0) return fail(s, "render: samples_per_px < 1");
@@ -1221,6 +1244,7 @@ int orc_render(orc_scene *s, const orc_camera *cb, const orc_render_params *p, d
     {
         Ctx c;
         init_ctx(c, *p);
+        c.flag_radius = flag_radius;
         if (c.rng.kind == ORC_RNG_MT64) c.rng.mt.seed(p->seed);
         Renderer R{cam, s->world.get(), s->lights.get(), c};
 #pragma omp for schedule(dynamic, 1)
@@ -1235,7 +1259,9 @@ int orc_render(orc_scene *s, const orc_camera *cb, const orc_render_params *p, d
                     c.rng.begin(STREAM_CAMERA, 0);
                     Ray ray = cam.get_ray(i, uint32_t(j), si, sj, c);
                     c.cnt[7]++;
+                    c.path_flag = false;
                     Color col = R.ray_color(ray, cam.max_depth);
+                    if (flagged && c.path_flag) flagged[size_t(j) * W + i] += 1; // rows belong to one thread each
                     film_sum[px] += col.r;
                     film_sum[px + 1] += col.g;
                     film_sum[px + 2] += col.b;
@@ -1258,6 +1284,7 @@ int orc_render(orc_scene *s, const orc_camera *cb, const orc_render_params *p, d
     if (error == 2) return fail(s, "render: lights object lacks pdf_value/random (reference: unimplemented!())");
     return 0;
 }
+} // namespace
 
 int orc_camera_rays(orc_scene *s, const orc_camera *cb, const orc_render_params *p, uint32_t n,
                     const uint32_t *pixel, const uint32_t *stratum, double *o, double *d, double *time) {

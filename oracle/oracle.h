@@ -103,6 +103,13 @@ int orc_prim_count(orc_scene *);
 int orc_render(orc_scene *, const orc_camera *, const orc_render_params *, double *film_sum,
                double *film_sumsq, uint64_t *counters);
 
+/* The same render, and per pixel how many of its samples' paths scattered off a sphere of radius <
+ * radius_below on their way (any material: the outgoing direction is built on the normal (p - c) / r,
+ * which carries a difference in the last bit of the hit point p multiplied by 1 / r), so these are the
+ * paths on which an fp32 render and this f64 one part ways.  flagged: W*H counts. */
+int orc_render_flagged(orc_scene *, const orc_camera *, const orc_render_params *, double *film_sum, double radius_below,
+                       uint32_t *flagged);
+
 /* camera rays as the device generates them (for fixed ray batches) */
 int orc_camera_rays(orc_scene *, const orc_camera *, const orc_render_params *, uint32_t n,
                     const uint32_t *pixel, const uint32_t *stratum, double *o, double *d, double *time);

@@ -69,6 +69,22 @@ def render(sb: SceneBuilder, cam: CameraSettings, mode=MODE_REF_EXACT, rng=RNG_P
     return film, sq, dict(zip(COUNTER_NAMES, list(cnt)))
 
 
+def render_flagged(sb: SceneBuilder, cam: CameraSettings, radius_below, mode=MODE_BOOK3, rng=RNG_PHILOX24, seed=1, threads=1):
+    """render() plus, per pixel, how many of its samples scattered off a sphere smaller than
+    `radius_below`: (film_sum (H,W,3) f64, counts (H,W) uint32)."""
+    cs = cam.to_struct()
+    p = RenderParams(mode, rng, seed, 0, 0, 1, threads, 0, 0, 0, 0)
+    H, W = cam.image_height, cam.image_width
+    film = np.zeros((H, W, 3), np.float64)
+    flagged = np.zeros((H, W), np.uint32)
+    lib.orc_render_flagged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint32)]
+    rc = lib.orc_render_flagged(sb.handle, C.byref(cs), C.byref(p), _dp(film), C.c_double(radius_below),
+                                flagged.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc < 0:
+        raise RuntimeError(lib.orc_last_error(sb.handle).decode())
+    return film, flagged
+
+
 def camera_rays(sb, cam: CameraSettings, pixel, stratum, seed=1, rng=RNG_PHILOX24):
     cs = cam.to_struct()
     p = RenderParams(0, rng, seed, 0, 0, 1, 1, 0, 0, 0, 0)

@@ -100,11 +100,12 @@ RT_MODE_REF_EXACT, RT_MODE_BOOK3 = 0, 1
 class RtAccelInfo(_Sized):
     _fields_ = [("struct_size", u32), ("kind", u32), ("nodes", u32), ("depth", u32), ("stack_entries", u32), ("cost", f64),
                 ("flat_quads", u32), ("flat_boxes", u32), ("flat_alone_spheres", u32), ("node_bytes", u32),
-                ("flat_boxes_aligned", u32), ("flat_boxes_upright", u32), ("flat_rects", u32)]
+                ("flat_boxes_aligned", u32), ("flat_boxes_upright", u32), ("flat_rects", u32), ("box_leaves", u32), ("leaves", u32),
+                ("post_tests", u32), ("reserved", u32), ("walk_cost", f64)]
 
 
 RT_BUILD_REFERENCE, RT_BUILD_SAH, RT_BUILD_AUTO = 0, 1, 2
-RT_BUILD_FP32_BOXES, RT_BUILD_BYTE_BOXES = 0x100, 0x200
+RT_BUILD_FP32_BOXES, RT_BUILD_BYTE_BOXES, RT_BUILD_NO_BOX_LEAVES, RT_BUILD_NO_POST_TESTS = 0x100, 0x200, 0x400, 0x800
 RT_FLAG_TIME_KERNELS = 1
 RT_FLAG_WAVEFRONT = 2
 RT_FLAG_REGROUP = 4

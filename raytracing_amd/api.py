@@ -273,13 +273,18 @@ class Device:
     def set_stream(self, hip_stream_ptr):
         self._check(self.lib.rt_set_stream(self.h, C.c_void_p(hip_stream_ptr)), "rt_set_stream")
 
-    def set_accel(self, builder="auto", width=4, fp32_boxes=None):
+    def set_accel(self, builder="auto", width=4, fp32_boxes=None, box_leaves=True, post_tests=True):
         """Structure built by the next upload: builder "reference" | "sah" | "auto", width 2 | 4;
         fp32_boxes: True = 128-byte wide nodes with fp32 child boxes, False = 64-byte nodes with byte
-        boxes, None = chosen by the size of the tree."""
+        boxes, None = chosen by the size of the tree; box_leaves=False keeps the six faces of an
+        axis-aligned box six quad leaves."""
         b = {"reference": _ffi.RT_BUILD_REFERENCE, "sah": _ffi.RT_BUILD_SAH, "auto": _ffi.RT_BUILD_AUTO}[builder]
         if fp32_boxes is not None:
             b |= _ffi.RT_BUILD_FP32_BOXES if fp32_boxes else _ffi.RT_BUILD_BYTE_BOXES
+        if not box_leaves:
+            b |= _ffi.RT_BUILD_NO_BOX_LEAVES
+        if not post_tests:  # primitives that enclose the scene stay in the tree
+            b |= _ffi.RT_BUILD_NO_POST_TESTS
         self._check(self.lib.rt_set_accel(self.h, b, width), "rt_set_accel")
 
     def accel_info(self):
@@ -287,7 +292,8 @@ class Device:
         self._check(self.lib.rt_get_accel_info(self.h, C.byref(a)), "rt_get_accel_info")
         return dict(kind=("flat", "bvh2", "bvh4")[a.kind], nodes=a.nodes, depth=a.depth, stack_entries=a.stack_entries, cost=a.cost,
                     flat_quads=a.flat_quads, flat_boxes=a.flat_boxes, flat_alone_spheres=a.flat_alone_spheres, node_bytes=a.node_bytes,
-                    flat_boxes_aligned=a.flat_boxes_aligned, flat_boxes_upright=a.flat_boxes_upright, flat_rects=a.flat_rects)
+                    flat_boxes_aligned=a.flat_boxes_aligned, flat_boxes_upright=a.flat_boxes_upright, flat_rects=a.flat_rects,
+                    box_leaves=a.box_leaves, leaves=a.leaves, post_tests=a.post_tests, walk_cost=a.walk_cost)
 
     def upload(self, scene: SceneBuilder):
         desc = scene.flatten()

@@ -14,6 +14,7 @@
 // Nodes are numbered breadth first.
 #pragma once
 #include "../../include/rt_amd.h"
+#include "rt_flat.h"
 #include "rt_leafword.h"
 
 #include <algorithm>
@@ -50,6 +51,19 @@ struct Node4Q {
     uint32_t child[4];
 };
 static_assert(sizeof(Node4Q) == 64, "quantised wide node is half a 128-byte line");
+
+// Six quads of one list that are the faces of a box along the world's axes, as one leaf of the wide
+// tree (RT_KIND_BOX): 48 bytes.  The planes are the coordinates the faces' own quad records hold, so the
+// slab test's t = (plane - o) / d is the quad test's own quotient for a unit normal along an axis, bit for
+// bit (ties between faces of neighbouring boxes fall as they do between the quads).
+struct WideBox {
+    float lo[3];
+    uint32_t ref_lo_x;
+    float hi[3];
+    uint32_t ref_hi_x;
+    uint32_t ref_lo_y, ref_lo_z, ref_hi_y, ref_hi_z;
+};
+static_assert(sizeof(WideBox) == 48, "three 16-byte loads per box");
 
 namespace accel {
 
@@ -102,6 +116,8 @@ struct Stats {
     // surface-area cost: expected boxes tested by a random ray that enters the root box =
     // 4 * sum over nodes of area(node) / area(root)
     double cost = 0.0;
+    // measured: mean work of walking a surface-to-surface segment through the tree (walk_cost), in node visits
+    double walk = 0.0;
 };
 
 struct Builder {
@@ -110,17 +126,68 @@ struct Builder {
     std::vector<Inner> inner;
     std::vector<int32_t> node_slot; // descriptor node index -> slot (memo: nodes may be shared)
     std::string error;
+    bool find_boxes = true;      // runs of six quads in a list that are an axis-aligned box become one leaf
+    std::vector<WideBox> boxes;  // the records of those leaves
+    std::vector<uint32_t> box_faces; // 6 quad refs per box, list order (for checks)
 
     explicit Builder(const rt_scene_desc *scene) : s(scene), node_slot(scene->n_nodes, -1) {}
 
-    // reference -> reference with the class of its material (see RT4_CLASS_SHIFT)
-    uint32_t with_class(uint32_t ref) const {
+    uint32_t class_of(uint32_t ref) const {
         const uint32_t kind = ref >> RT_REF_KIND_SHIFT, idx = ref & RT_REF_INDEX_MASK;
         const uint32_t mat = kind == RT_KIND_QUAD ? s->quads[idx].mat : kind == RT_KIND_SPHERE ? s->spheres[idx].mat : s->media[idx].mat;
         const uint32_t type = s->materials[mat].type;
-        const uint32_t cls = type == RT_MAT_LIGHT ? RT4_CLASS_END : type == RT_MAT_METAL ? RT4_CLASS_METAL
-                                                                 : type == RT_MAT_DIELECTRIC ? RT4_CLASS_GLASS : RT4_CLASS_DIFFUSE;
-        return ref | (cls << RT4_CLASS_SHIFT);
+        return type == RT_MAT_LIGHT ? RT4_CLASS_END : type == RT_MAT_METAL ? RT4_CLASS_METAL : type == RT_MAT_DIELECTRIC ? RT4_CLASS_GLASS : RT4_CLASS_DIFFUSE;
+    }
+
+    // refs[0..6) of a list: the faces of one box along the world's axes, all of one material class?
+    // Then the box's record is appended and its leaf reference returned, else RT_REF_NONE.
+    uint32_t match_wide_box(const uint32_t *refs) {
+        const rt_quad *faces[6];
+        for (int i = 0; i < 6; ++i) {
+            if ((refs[i] >> RT_REF_KIND_SHIFT) != RT_KIND_QUAD) return RT_REF_NONE;
+            faces[i] = &s->quads[refs[i] & RT_REF_INDEX_MASK];
+            if (class_of(refs[i]) != class_of(refs[0])) return RT_REF_NONE;
+        }
+        float rec[32];
+        if (!flat::match_box(faces, refs, 6, rec)) return RT_REF_NONE;
+        uint32_t cls;
+        std::memcpy(&cls, &rec[24], 4);
+        if (cls != RT_BOX_ALIGNED) return RT_REF_NONE;
+        if (boxes.size() >= (1u << RT4_CLASS_SHIFT)) return RT_REF_NONE;
+        WideBox b;
+        uint32_t r[6]; // lo x y z, hi x y z
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = rec[12 + 2 * a], b.hi[a] = rec[13 + 2 * a];
+            std::memcpy(&r[a], &rec[18 + a], 4);
+            std::memcpy(&r[3 + a], &rec[21 + a], 4);
+            if (!(b.lo[a] < b.hi[a])) return RT_REF_NONE;
+        }
+        b.ref_lo_x = r[0], b.ref_lo_y = r[1], b.ref_lo_z = r[2], b.ref_hi_x = r[3], b.ref_hi_y = r[4], b.ref_hi_z = r[5];
+        // match_box lets a face differ from the box by 1e-5 of the scene's scale (enough for a scan that is
+        // checked against the quads it replaces at upload of a dozen quads); here every face must span the
+        // box to within fp32 rounding of its own corners, so that the slab test and the six interior tests
+        // can differ only where those differ among themselves.
+        for (int i = 0; i < 6; ++i)
+            for (int a = 0; a < 3; ++a) {
+                if (std::fabs(faces[i]->n[a]) == 1.0f) continue; // its normal's axis
+                double mn = 1e300, mx = -1e300;
+                for (int c = 0; c < 4; ++c) {
+                    const double x = double(faces[i]->q[a]) + ((c & 1) ? double(faces[i]->u[a]) : 0.0) + ((c & 2) ? double(faces[i]->v[a]) : 0.0);
+                    mn = std::min(mn, x), mx = std::max(mx, x);
+                }
+                const double eps = 4.0 * std::ldexp(std::max(std::fabs(double(b.lo[a])), std::fabs(double(b.hi[a]))), -23);
+                if (std::fabs(mn - b.lo[a]) > eps || std::fabs(mx - b.hi[a]) > eps) return RT_REF_NONE;
+            }
+        boxes.push_back(b);
+        box_faces.insert(box_faces.end(), refs, refs + 6);
+        return (RT_KIND_BOX << RT_REF_KIND_SHIFT) | uint32_t(boxes.size() - 1);
+    }
+
+    // reference -> reference with the class of its material (see RT4_CLASS_SHIFT)
+    uint32_t with_class(uint32_t ref) const {
+        if ((ref >> RT_REF_KIND_SHIFT) == RT_KIND_BOX) // its faces share one class (match_wide_box)
+            return ref | (class_of(box_faces[6 * size_t(ref & RT_REF_INDEX_MASK)]) << RT4_CLASS_SHIFT);
+        return ref | (class_of(ref) << RT4_CLASS_SHIFT);
     }
 
     Box prim_box(uint32_t ref) const {
@@ -146,6 +213,8 @@ struct Builder {
         } else if (kind == RT_KIND_MEDIUM) {
             const rt_medium &m = s->media[idx];
             for (uint32_t k = 0; k < m.count; ++k) b.add(prim_box(s->refs[m.first + k]));
+        } else if (kind == RT_KIND_BOX) { // what its six faces' boxes cover
+            for (int k = 0; k < 6; ++k) b.add(prim_box(box_faces[6 * size_t(idx) + k]));
         }
         return b;
     }
@@ -252,6 +321,14 @@ struct Builder {
             }
             std::vector<int32_t> items;
             for (uint32_t k = 0; k < n.count; ++k) {
+                if (find_boxes && k + 6 <= n.count) {
+                    const uint32_t box = match_wide_box(s->refs + n.left + k);
+                    if (box != RT_REF_NONE) {
+                        items.push_back(new_slot(box, -1, prim_box(box)));
+                        k += 5;
+                        continue;
+                    }
+                }
                 int32_t c = from_ref(s->refs[n.left + k], depth + 1);
                 if (c < 0) return -1;
                 items.push_back(c);
@@ -266,6 +343,55 @@ struct Builder {
         }
         node_slot[idx] = out;
         return out;
+    }
+
+    // The binary tree without the leaves whose slot is marked in `drop`; boxes above a dropped leaf are
+    // made again from what is left.  Returns the new top, or -1 when nothing is left.
+    int32_t prune(int32_t slot, const std::vector<char> &drop) {
+        if (slots[slot].node < 0) return drop[slot] ? -1 : slot;
+        const Inner in = inner[slots[slot].node];
+        const int32_t a = prune(in.a, drop), b = prune(in.b, drop);
+        if (a == in.a && b == in.b) return slot;
+        if (a < 0) return b;
+        if (b < 0) return a;
+        return join(a, b);
+    }
+
+    // Primitives that enclose the rest of the scene -- a fog that fills the world ("The Next Week"'s final
+    // scene wraps everything in a ConstantMedium of radius 5000) -- cannot be culled by any box: every ray
+    // tests them, at whatever moment its walk through the tree gets there, with the few lanes of the wave
+    // that are at a primitive just then.  They leave the tree and are tested once per ray when its walk has
+    // ended (DScene::post_ref), with every lane that has finished -- the closest hit does not depend on the
+    // order of the tests.  At most two; spheres and media only (a quad's box is flat).
+    std::vector<uint32_t> take_enclosing(int32_t &top) {
+        std::vector<uint32_t> post;
+        if (slots[top].node < 0) return post;
+        std::vector<int32_t> prims;
+        collect_prims(top, prims);
+        Box all;
+        for (int32_t p : prims) all.add(slots[p].box);
+        std::vector<char> drop(slots.size(), 0);
+        for (int32_t p : prims) {
+            const uint32_t kind = slots[p].ref >> RT_REF_KIND_SHIFT;
+            if ((kind != RT_KIND_SPHERE && kind != RT_KIND_MEDIUM) || post.size() >= 2) continue;
+            if (slots[p].box.area() < 0.9 * all.area()) continue;
+            Box others;
+            for (int32_t o : prims)
+                if (o != p && !drop[o]) others.add(slots[o].box);
+            if (!others.valid()) continue; // it is all there is
+            bool encloses = true;
+            for (int a = 0; a < 3; ++a) encloses = encloses && slots[p].box.lo[a] <= others.lo[a] && slots[p].box.hi[a] >= others.hi[a];
+            if (!encloses) continue;
+            drop[p] = 1;
+            post.push_back(with_class(slots[p].ref));
+        }
+        if (!post.empty()) {
+            drop.resize(slots.size(), 0);
+            const int32_t t = prune(top, drop);
+            if (t < 0) post.clear(); // (cannot happen: `others` was never empty)
+            else top = t;
+        }
+        return post;
     }
 
     void collect_prims(int32_t slot, std::vector<int32_t> &out) const {
@@ -393,22 +519,92 @@ inline double sa_cost(const std::vector<Node4> &nodes) {
     return 4.0 * sum / ra;
 }
 
+// What a closest-hit search through the tree costs, measured instead of modelled: the rays of a path
+// tracer run from surface to surface, so segments between random points of two leaves' boxes (leaves
+// drawn by surface area) are walked through the tree and what they touch is counted -- a node visit 1, a leaf by its kind's test
+// relative to a visit (instruction counts of the device code).  The surface-area cost above assumes rays
+// uniform through the root box; one far-out primitive (a fog around the world) inflates that box and the
+// cost no longer tells two trees of the actual scene apart.  Deterministic.
+inline double walk_cost(const std::vector<Node4> &nodes, uint32_t n_segments = 2048) {
+    if (nodes.empty()) return 0.0;
+    std::vector<Box> leaves;
+    for (const Node4 &n : nodes)
+        for (int k = 0; k < 4; ++k)
+            if (n.child[k] != RT_REF_NONE && (n.child[k] >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
+                Box b;
+                for (int a = 0; a < 3; ++a) b.lo[a] = n.lo[a][k], b.hi[a] = n.hi[a][k];
+                leaves.push_back(b);
+            }
+    if (leaves.size() < 2) return 1.0;
+    // a leaf is an end of a segment as often as its surface says: rays end on surfaces by their area
+    std::vector<double> upto(leaves.size());
+    double area_sum = 0.0;
+    for (size_t i = 0; i < leaves.size(); ++i) upto[i] = (area_sum += std::max(leaves[i].area(), 1e-300));
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { // splitmix64 -> [0, 1)
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return double((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0);
+    };
+    auto point_in = [&](const Box &b, double p[3]) {
+        for (int a = 0; a < 3; ++a) p[a] = double(b.lo[a]) + rnd() * (double(b.hi[a]) - double(b.lo[a]));
+    };
+    const double leaf_weight[8] = {0.0, 0.5, 0.6, 1.6, 0.45, 0.0, 0.0, 0.0}; // by kind: quad, sphere, medium, box
+    double total = 0.0;
+    std::vector<uint32_t> stack;
+    for (uint32_t i = 0; i < n_segments; ++i) {
+        double o[3], e[3], inv[3];
+        auto pick = [&]() { return std::min(size_t(std::lower_bound(upto.begin(), upto.end(), rnd() * area_sum) - upto.begin()), leaves.size() - 1); };
+        point_in(leaves[pick()], o);
+        point_in(leaves[pick()], e);
+        for (int a = 0; a < 3; ++a) inv[a] = 1.0 / (e[a] - o[a]); // +-inf for a segment along an axis
+        stack.assign(1, 0u);
+        while (!stack.empty()) {
+            const Node4 &n = nodes[stack.back()];
+            stack.pop_back();
+            total += 1.0;
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c = n.child[k];
+                if (c == RT_REF_NONE) continue;
+                double t0 = 0.0, t1 = 1.0;
+                for (int a = 0; a < 3; ++a) {
+                    double x0 = (double(n.lo[a][k]) - o[a]) * inv[a], x1 = (double(n.hi[a][k]) - o[a]) * inv[a];
+                    if (x0 != x0 || x1 != x1) continue; // on a plane it runs along: no constraint
+                    if (x0 > x1) std::swap(x0, x1);
+                    t0 = std::max(t0, x0), t1 = std::min(t1, x1);
+                }
+                if (t0 > t1) continue;
+                if ((c >> RT_REF_KIND_SHIFT) == RT_KIND_NODE) stack.push_back(c & RT_REF_INDEX_MASK);
+                else total += leaf_weight[(c >> RT_REF_KIND_SHIFT) & 7u];
+            }
+        }
+    }
+    return total / n_segments;
+}
+
 // Builds the wide BVH of the (validated) scene.  builder: RT_BUILD_REFERENCE keeps the grouping
 // of the descriptor's binary nodes, RT_BUILD_SAH regroups all primitives, RT_BUILD_AUTO builds both
-// and keeps the one with the lower surface-area cost.  Returns "" or an error.
+// and keeps the one that is cheaper to walk (walk_cost).  boxes / box_faces: where the records of box
+// leaves go (null: six quads stay six leaves); post: where primitives that enclose the scene go (null:
+// they stay in the tree).  Returns "" or an error.
 inline std::string build_wide_bvh(const rt_scene_desc *s, uint32_t builder, std::vector<Node4> &nodes, uint32_t &root,
-                                  Stats &st) {
+                                  Stats &st, std::vector<WideBox> *boxes = nullptr, std::vector<uint32_t> *box_faces = nullptr,
+                                  std::vector<uint32_t> *post = nullptr) {
     if (s->n_quads >= (1u << RT4_CLASS_SHIFT) || s->n_spheres >= (1u << RT4_CLASS_SHIFT) || s->n_media >= (1u << RT4_CLASS_SHIFT))
         return "more than 2^27 primitives of one kind";
     Builder b(s);
+    b.find_boxes = boxes != nullptr; // a caller without room for the records gets quads only
     b.slots.reserve(size_t(s->n_quads + s->n_spheres + s->n_media) * 2 + 16);
-    const int32_t top = b.from_ref(s->root, 0);
+    int32_t top = b.from_ref(s->root, 0);
     if (top < 0) return b.error;
+    if (post) *post = b.take_enclosing(top);
     auto finish = [&](int32_t t, std::vector<Node4> &out, Stats &o) {
         o = Stats();
         root = b.collapse(t, out, o);
         o.stack_need = stack_need(out);
         o.cost = sa_cost(out);
+        o.walk = walk_cost(out);
     };
     if (builder != RT_BUILD_SAH) finish(top, nodes, st);
     if (builder != RT_BUILD_REFERENCE && b.slots[top].node >= 0) {
@@ -418,10 +614,12 @@ inline std::string build_wide_bvh(const rt_scene_desc *s, uint32_t builder, std:
         std::vector<Node4> alt;
         Stats alt_st;
         finish(sah_top, alt, alt_st);
-        if (builder == RT_BUILD_SAH || alt_st.cost < st.cost) nodes.swap(alt), st = alt_st;
+        if (builder == RT_BUILD_SAH || alt_st.walk < st.walk) nodes.swap(alt), st = alt_st;
     } else if (builder == RT_BUILD_SAH) {
         finish(top, nodes, st);
     }
+    if (boxes) boxes->swap(b.boxes);
+    if (box_faces) box_faces->swap(b.box_faces);
     return "";
 }
 
@@ -484,8 +682,10 @@ inline std::string verify_quantised(const std::vector<Node4> &nodes, const std::
 // Structural check of a built tree against its scene: every primitive the descriptor's world
 // reaches is a leaf exactly as often as the descriptor reaches it, every child box contains what
 // is below it, indices point forward.  Returns "" or what is wrong.
-inline std::string verify_wide_bvh(const rt_scene_desc *s, const std::vector<Node4> &nodes) {
+inline std::string verify_wide_bvh(const rt_scene_desc *s, const std::vector<Node4> &nodes, const std::vector<WideBox> &boxes = {},
+                                   const std::vector<uint32_t> &box_faces = {}, const std::vector<uint32_t> &post = {}) {
     if (nodes.empty()) return "no nodes";
+    if (box_faces.size() != 6 * boxes.size()) return "box records and their face lists differ in number";
     // leaves the descriptor reaches (with multiplicity)
     std::vector<uint32_t> want;
     {
@@ -505,6 +705,7 @@ inline std::string verify_wide_bvh(const rt_scene_desc *s, const std::vector<Nod
         }
     }
     Builder b(s);
+    b.boxes = boxes, b.box_faces = box_faces;
     std::vector<uint32_t> got;
     std::vector<Box> below(nodes.size());
     for (size_t i = nodes.size(); i-- > 0;) {
@@ -519,14 +720,35 @@ inline std::string verify_wide_bvh(const rt_scene_desc *s, const std::vector<Nod
                 if (j <= i || j >= nodes.size()) return "child index does not point forward";
                 content = below[j];
             } else {
-                if (c != b.with_class(c & ~RT4_CLASS_MASK)) return "leaf does not carry the class of its material";
-                content = b.prim_box(c & ~RT4_CLASS_MASK);
-                got.push_back(c & ~RT4_CLASS_MASK);
+                const uint32_t leaf = c & ~RT4_CLASS_MASK;
+                if ((leaf >> RT_REF_KIND_SHIFT) == RT_KIND_BOX) {
+                    const uint32_t bi = leaf & RT_REF_INDEX_MASK;
+                    if (bi >= boxes.size()) return "box leaf outside the box records";
+                    // the record's planes and face refs are those of its six quads
+                    const WideBox &wb = boxes[bi];
+                    const uint32_t refs[6] = {wb.ref_lo_x, wb.ref_lo_y, wb.ref_lo_z, wb.ref_hi_x, wb.ref_hi_y, wb.ref_hi_z};
+                    for (int f = 0; f < 6; ++f) {
+                        const int axis = f % 3;
+                        if ((refs[f] >> RT_REF_KIND_SHIFT) != RT_KIND_QUAD || (refs[f] & RT_REF_INDEX_MASK) >= s->n_quads) return "box face is not a quad";
+                        if (std::find(&box_faces[6 * size_t(bi)], &box_faces[6 * size_t(bi)] + 6, refs[f]) == &box_faces[6 * size_t(bi)] + 6) return "box face not among the box's quads";
+                        const rt_quad &q = s->quads[refs[f] & RT_REF_INDEX_MASK];
+                        if (std::fabs(q.n[axis]) != 1.0f || q.q[axis] != (f < 3 ? wb.lo[axis] : wb.hi[axis])) return "box plane differs from its face's quad";
+                    }
+                    for (int f = 0; f < 6; ++f) got.push_back(box_faces[6 * size_t(bi) + f]);
+                } else {
+                    got.push_back(leaf);
+                }
+                if (c != b.with_class(leaf)) return "leaf does not carry the class of its material";
+                content = b.prim_box(leaf);
             }
             for (int a = 0; a < 3; ++a)
                 if (!(stored.lo[a] <= content.lo[a] && stored.hi[a] >= content.hi[a])) return "child box does not contain its content";
             below[i].add(stored);
         }
+    }
+    for (uint32_t r : post) { // tested after the walk instead of inside it
+        if (r != b.with_class(r & ~RT4_CLASS_MASK)) return "a primitive tested after the walk does not carry the class of its material";
+        got.push_back(r & ~RT4_CLASS_MASK);
     }
     std::sort(want.begin(), want.end());
     std::sort(got.begin(), got.end());

@@ -52,6 +52,9 @@ struct rt_handle {
     size_t dyn_lds4() const { return size_t(stack4) * BLOCK * sizeof(uint32_t) + size_t(lds_nodes4) * node4_bytes(); }
     enum { BOXES_AUTO = 0, BOXES_FP32 = 1, BOXES_BYTE = 2 };
     int boxes = BOXES_AUTO;                 // rt_set_accel: RT_BUILD_FP32_BOXES / RT_BUILD_BYTE_BOXES
+    bool box_leaves = true;                 // rt_set_accel: RT_BUILD_NO_BOX_LEAVES clears it
+    bool post_prims = true;                 // rt_set_accel: RT_BUILD_NO_POST_TESTS clears it
+    uint32_t n_box_leaves = 0;              // leaves of kind RT_KIND_BOX in the tree searched
     accel::Stats accel_stats{};
     uint32_t has_media = 0, n_prims = 0, alone_spheres = 0, n_quads = 0, n_spheres = 0, n_materials = 0;
     bool has_specular = false;
@@ -773,13 +776,14 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     struct {
         bool flat;
         int accel;
-        uint32_t stack4, lds_nodes4;
+        uint32_t stack4, lds_nodes4, n_box_leaves;
         accel::Stats stats;
-    } const keep{h->flat, h->accel, h->stack4, h->lds_nodes4, h->accel_stats};
+    } const keep{h->flat, h->accel, h->stack4, h->lds_nodes4, h->n_box_leaves, h->accel_stats};
     auto rollback = [&]() {
         for (void *p : h->scene_allocs) (void)hipFree(p);
         h->scene_allocs.swap(old_allocs);
         h->flat = keep.flat, h->accel = keep.accel, h->stack4 = keep.stack4, h->lds_nodes4 = keep.lds_nodes4, h->accel_stats = keep.stats;
+        h->n_box_leaves = keep.n_box_leaves;
         return -1;
     };
     DScene d{};
@@ -790,6 +794,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     const float *dnv;
     const Node4 *dn4 = nullptr;
     const Node4Q *dn4q = nullptr;
+    const WideBox *dwb = nullptr;
     // device copy of the materials: a SolidColor texture is folded into the material record
     // (albedo + pad = 1) so that shading such a surface does not chase the texture record
     std::vector<rt_material> mats(s->materials, s->materials + s->n_materials);
@@ -841,13 +846,16 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     // structure the kernels will search
     std::vector<Node4> nodes4;
     std::vector<Node4Q> nodes4q;
+    std::vector<WideBox> wide_boxes; // the tree's leaves of kind RT_KIND_BOX
+    std::vector<uint32_t> post;      // primitives that enclose the scene: tested after the walk (test_post)
     h->stack4 = h->lds_nodes4 = 0;
     h->accel_stats = accel::Stats();
     if (h->flat) {
         h->accel = ACCEL_FLAT;
     } else if (h->width == 4) {
         uint32_t root4 = 0;
-        std::string err = accel::build_wide_bvh(s, h->build, nodes4, root4, h->accel_stats);
+        std::string err = accel::build_wide_bvh(s, h->build, nodes4, root4, h->accel_stats, h->box_leaves ? &wide_boxes : nullptr, nullptr,
+                                                h->post_prims ? &post : nullptr);
         if (!err.empty()) {
             fail(h, "rt_upload_scene: " + err);
             return rollback();
@@ -874,6 +882,8 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
             h->lds_nodes4 = stack_bytes < budget ? uint32_t(std::min<size_t>(nodes4.size(), (budget - stack_bytes) / h->node4_bytes())) : 0u;
         } else {
             nodes4.clear(); // too deep for the LDS stack of the wide traversal: binary nodes as given
+            wide_boxes.clear();
+            post.clear();
             h->accel = ACCEL_BVH2;
         }
     } else {
@@ -889,6 +899,8 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
             return rollback();
         }
     }
+    d.n_post = uint32_t(post.size());
+    for (size_t i = 0; i < post.size() && i < 2; ++i) d.post_ref[i] = post[i];
     d.n_nodes4 = uint32_t(nodes4.size());
     d.stack4 = h->stack4;
     d.lds_nodes4 = h->lds_nodes4;
@@ -902,6 +914,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     if (upload(h, flat_boxes.data(), flat_boxes.size(), &d.flat_boxes) || upload(h, s->nodes, s->n_nodes, &d.nodes) || upload(h, s->refs, s->n_refs, &d.refs) ||
         upload(h, s->quads, s->n_quads, &dq) || upload(h, spheres.data(), spheres.size(), &ds) ||
         upload(h, flat_quads.data(), flat_quads.size(), &d.flat_quads) || upload(h, flat_pairs.data(), flat_pairs.size(), &d.flat_pairs) || (h->accel == ACCEL_BVH4Q ? upload(h, nodes4q.data(), nodes4q.size(), &dn4q) : upload(h, nodes4.data(), nodes4.size(), &dn4)) ||
+        upload(h, wide_boxes.data(), wide_boxes.size(), &dwb) ||
         upload(h, flat_other.data(), flat_other.size(), &d.flat_other) || upload(h, fp.spheres.data(), fp.spheres.size(), &d.flat_spheres) ||
         upload(h, s->media, s->n_media, &d.media) || upload(h, mats.data(), mats.size(), &d.mats) ||
         upload(h, s->textures, s->n_textures, &d.texs) || upload(h, s->light_refs, s->n_lights, &d.light_refs) || upload(h, light_recs.data(), light_recs.size(), &d_light_recs) ||
@@ -913,6 +926,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     d.spheres = reinterpret_cast<const float4 *>(ds);
     d.noise_vec = reinterpret_cast<const float4 *>(dnv);
     d.nodes4 = h->accel == ACCEL_BVH4Q ? reinterpret_cast<const float4 *>(dn4q) : reinterpret_cast<const float4 *>(dn4);
+    d.wide_boxes = reinterpret_cast<const float4 *>(dwb);
     d.root = s->root;
     d.n_lights = s->n_lights;
     d.lights_kind = s->lights_kind;
@@ -931,6 +945,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     h->sc = d;
     h->have_scene = true;
     h->has_media = s->n_media ? 1u : 0u;
+    h->n_box_leaves = uint32_t(wide_boxes.size());
     h->n_quads = s->n_quads, h->n_spheres = s->n_spheres, h->n_materials = s->n_materials;
     h->alone_spheres = 0;
     for (const rt_sphere &sp : spheres) h->alone_spheres += sp.pad;
@@ -956,7 +971,8 @@ int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width) {
     if (!h) return -1;
     if ((builder & RT_BUILD_FP32_BOXES) && (builder & RT_BUILD_BYTE_BOXES)) return fail(h, "rt_set_accel: fp32 boxes or byte boxes, not both");
     const int boxes = (builder & RT_BUILD_FP32_BOXES) ? rt_handle::BOXES_FP32 : (builder & RT_BUILD_BYTE_BOXES) ? rt_handle::BOXES_BYTE : rt_handle::BOXES_AUTO;
-    builder &= ~(RT_BUILD_FP32_BOXES | RT_BUILD_BYTE_BOXES);
+    const bool box_leaves = !(builder & RT_BUILD_NO_BOX_LEAVES), post_prims = !(builder & RT_BUILD_NO_POST_TESTS);
+    builder &= ~(RT_BUILD_FP32_BOXES | RT_BUILD_BYTE_BOXES | RT_BUILD_NO_BOX_LEAVES | RT_BUILD_NO_POST_TESTS);
     if (builder > RT_BUILD_AUTO) return fail(h, "rt_set_accel: unknown builder");
     if (width != 2 && width != 4) return fail(h, "rt_set_accel: width must be 2 or 4");
     if (width == 2 && builder != RT_BUILD_REFERENCE)
@@ -964,6 +980,8 @@ int rt_set_accel(rt_handle *h, uint32_t builder, uint32_t width) {
     h->build = builder;
     h->width = width;
     h->boxes = boxes;
+    h->box_leaves = box_leaves;
+    h->post_prims = post_prims;
     return 0;
 }
 
@@ -976,10 +994,13 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
     rt_handle tmp; // validate_scene only records its message in the handle
     if (validate_scene(&tmp, scene)) return say(tmp.err);
     std::vector<Node4> nodes;
+    std::vector<WideBox> boxes;
+    std::vector<uint32_t> box_faces;
     uint32_t root = 0;
     accel::Stats st;
-    std::string e = accel::build_wide_bvh(scene, builder, nodes, root, st);
-    if (e.empty()) e = accel::verify_wide_bvh(scene, nodes);
+    std::vector<uint32_t> post;
+    std::string e = accel::build_wide_bvh(scene, builder, nodes, root, st, &boxes, &box_faces, &post);
+    if (e.empty()) e = accel::verify_wide_bvh(scene, nodes, boxes, box_faces, post);
     if (!e.empty()) return say("rt_accel_selftest: " + e);
     if (out) {
         rt_accel_info a{};
@@ -992,6 +1013,7 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
         a.flat_quads = fp.n_quads, a.flat_boxes = uint32_t(fp.boxes.size() / 32), a.flat_alone_spheres = uint32_t(fp.alone_spheres.size());
         a.flat_boxes_aligned = fp.n_boxes_aligned, a.flat_boxes_upright = fp.n_boxes_upright;
         a.flat_rects = uint32_t(fp.rects.size() / 8);
+        a.box_leaves = uint32_t(boxes.size()), a.leaves = st.leaves, a.post_tests = uint32_t(post.size()), a.walk_cost = st.walk;
         a.node_bytes = uint32_t(sizeof(Node4Q));
         std::vector<Node4Q> q;
         accel::quantise_nodes(nodes, q);
@@ -1020,6 +1042,8 @@ int rt_get_accel_info(rt_handle *h, rt_accel_info *out) {
     a.flat_boxes_aligned = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_aligned : 0u;
     a.flat_boxes_upright = h->accel == ACCEL_FLAT ? h->sc.n_flat_boxes_upright : 0u;
     a.flat_rects = h->accel == ACCEL_FLAT ? h->sc.n_flat_rects : 0u;
+    a.box_leaves = wide ? h->n_box_leaves : 0u, a.leaves = wide ? h->accel_stats.leaves : 0u;
+    a.post_tests = wide ? h->sc.n_post : 0u, a.walk_cost = wide ? h->accel_stats.walk : 0.0;
     const std::string bad = write_sized(a, out, "rt_accel_info");
     return bad.empty() ? 0 : fail(h, "rt_get_accel_info: " + bad);
 }

@@ -84,6 +84,7 @@ struct DScene {
     // 4-wide BVH derived at upload (rt_accel.h), root = node 0: 8 float4 per node (fp32 boxes) or 4
     // (quantised boxes)
     const float4 *nodes4;
+    const float4 *wide_boxes; // leaves of kind RT_KIND_BOX: 3 float4 per box (WideBox, rt_accel.h)
     uint32_t root, n_lights, lights_kind, n_nodes, n_flat_quads, n_flat_pairs, n_flat_other, n_nodes4, n_flat_boxes;
     uint32_t n_flat_boxes_aligned, n_flat_boxes_upright; // the box records' first two classes (scan_flat)
     // rectangles along the world's axes: 8 floats each at the head of flat_boxes, padded to 32; sorted
@@ -92,6 +93,9 @@ struct DScene {
     uint32_t n_flat_spheres;
     // dynamic LDS of the wide traversal: [stack4][BLOCK] stack entries, then the first lds_nodes4 nodes
     uint32_t stack4, lds_nodes4;
+    // wide tree: primitives that enclose the rest of the scene (a fog around the world) are not in the
+    // tree; every ray tests them when its walk has ended (test_post).  Leaf words, class bits included.
+    uint32_t n_post, post_ref[2];
 };
 
 // which structure a kernel instance searches
@@ -161,7 +165,9 @@ __device__ __forceinline__ bool hit_quad(const float4 *__restrict__ Q, V3 o, V3 
     float denom = dot(n, d);
     if (fabsf(denom) < 1e-8f) return false;
     V3 qo = mk(q0) - o;
-    float tt = dot(n, qo) / denom; // (D - n.o)/denom with the subtraction done first
+    // (D - n.o)/denom with the subtraction done first; v_rcp_f32 and a product (1.5 ulp) -- the same
+    // two roundings hit_wide_box makes for a face along a world axis, so equal planes give equal t
+    float tt = dot(n, qo) * rcp(denom);
     if (!(tt >= tlo && tt <= thi)) return false;
     float4 q2 = load4<UNIFORM>(Q, 2), q3 = load4<UNIFORM>(Q, 3);
     V3 ph = fma3(d, tt, -qo);
@@ -188,6 +194,15 @@ __device__ __forceinline__ bool hit_quad(const float4 *__restrict__ Q, V3 o, V3 
 // its way, for callers that have only the hit point.
 __device__ __forceinline__ void quad_uv(const float4 *__restrict__ Q, V3 p, float &a, float &b) {
     const V3 ph = p - mk(Q[0]);
+    a = dot(ph, mk(Q[2]));
+    b = dot(ph, mk(Q[3]));
+}
+
+// The same for callers that have the ray and t: hit_quad's own arithmetic, bit for bit (a hit that came
+// from a box leaf of the wide tree carries no (alpha, beta); see hit_wide_box).
+__device__ __forceinline__ void quad_uv_ray(const float4 *__restrict__ Q, V3 o, V3 d, float t, float &a, float &b) {
+    const V3 qo = mk(Q[0]) - o;
+    const V3 ph = fma3(d, t, -qo);
     a = dot(ph, mk(Q[2]));
     b = dot(ph, mk(Q[3]));
 }
@@ -358,13 +373,54 @@ __device__ __forceinline__ bool hit_medium(SceneRef sc, uint32_t idx, V3 o, V3 d
     return true;
 }
 
+// A box along the world's axes whose six faces are quads of the scene (leaf kind RT_KIND_BOX of the
+// wide tree; box3, hittable.rs:398-455): the six quad tests in one.  The ray crosses the faces' planes
+// where the quad tests put their hits -- t = (plane - o) * rcp(d) is hit_quad's own arithmetic for a unit
+// normal along an axis -- and of a convex box only the first crossing past tlo can be the closest hit:
+// the entry face, or the exit face for a ray that starts inside or on the entry face.  inv = 1/d per
+// axis.  Returns the face's quad ref in `face`.  t in [tlo, thi] closed, like a quad's.
+__device__ __forceinline__ bool hit_wide_box(const float4 *__restrict__ B, V3 o, V3 d, V3 inv, float tlo, float thi,
+                                             uint32_t origin_ref, float &t, uint32_t &face) {
+    const float4 b0 = B[0], b1 = B[1], b2 = B[2];
+    const float xl = (b0.x - o.x) * inv.x, xh = (b1.x - o.x) * inv.x;
+    const float yl = (b0.y - o.y) * inv.y, yh = (b1.y - o.y) * inv.y;
+    const float zl = (b0.z - o.z) * inv.z, zh = (b1.z - o.z) * inv.z;
+    // a ray parallel to an axis: +-inf, or NaN when it lies in a plane; min/max drop a NaN operand,
+    // which leaves that plane out -- the quad test rejects such a face as parallel (|denom| < 1e-8)
+    const float xn = fminf(xl, xh), xf = fmaxf(xl, xh), yn = fminf(yl, yh), yf = fmaxf(yl, yh), zn = fminf(zl, zh), zf = fmaxf(zl, zh);
+    const float t_near = fmaxf(fmaxf(xn, yn), zn), t_far = fminf(fminf(xf, yf), zf);
+    // the face on each axis the ray enters / leaves through follows from the direction's sign
+    const bool ux = d.x > 0.0f, uy = d.y > 0.0f, uz = d.z > 0.0f;
+    const uint32_t rlx = fbits(b0.w), rhx = fbits(b1.w), rly = fbits(b2.x), rlz = fbits(b2.y), rhy = fbits(b2.z), rhz = fbits(b2.w);
+    const uint32_t in_x = ux ? rlx : rhx, in_y = uy ? rly : rhy, in_z = uz ? rlz : rhz;
+    const uint32_t out_x = ux ? rhx : rlx, out_y = uy ? rhy : rly, out_z = uz ? rhz : rlz;
+    const uint32_t near_ref = xn >= fmaxf(yn, zn) ? in_x : (yn >= zn ? in_y : in_z);
+    const uint32_t far_ref = xf <= fminf(yf, zf) ? out_x : (yf <= zf ? out_y : out_z);
+    const bool use_near = (t_near >= tlo) & (near_ref != origin_ref);
+    const float tc = use_near ? t_near : t_far;
+    const uint32_t rcand = use_near ? near_ref : far_ref;
+    // (the quad test's rejection of a ray parallel to the face needs no word here: such a ray's crossings
+    // of that axis are +-huge and never the first crossing of a hit)
+    if (!((t_near <= t_far) & (tc >= tlo) & (tc <= thi) & (rcand != origin_ref))) return false;
+    t = tc;
+    face = rcand;
+    return true;
+}
+
 template <bool UNIFORM = false>
 __device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, float time, float tlo,
-                                          uint32_t origin_ref, const RayCtx &rc, Best &best) {
+                                          uint32_t origin_ref, const RayCtx &rc, Best &best, V3 inv = V3{0.f, 0.f, 0.f}) {
     uint32_t kind = r >> RT_REF_KIND_SHIFT, idx = r & RT_REF_INDEX_MASK;
     float t, a = 0.f, b = 0.f;
     bool h;
-    if (kind == RT_KIND_QUAD) {
+    if (kind == RT_KIND_BOX) { // wide tree only (the caller passes inv = 1/d)
+        uint32_t face = RT_REF_NONE;
+        h = hit_wide_box(sc.wide_boxes + 3 * idx, o, d, inv, tlo, best.t, origin_ref, t, face);
+        // between coincident faces of two boxes the later quad wins, as between two quads (below)
+        if (h && t == best.t && (best.ref >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD && best.ref > face) h = false;
+        if (h) r = face;
+        a = b = __builtin_nanf(""); // (alpha, beta) of the face: made from the hit point where a material asks (shade_emit)
+    } else if (kind == RT_KIND_QUAD) {
         // a ray leaving a planar primitive cannot meet it again; the reference rejects the
         // t ~ 0 root through its 0.001 lower bound, which fp32 at scene scale cannot resolve
         if (r == origin_ref) return;
@@ -702,12 +758,25 @@ __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float 
         if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
             // a leaf's word carries the class of its material above the index (rt_accel.h)
             const uint32_t before = best.ref;
-            test_prim(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best);
+            test_prim(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best, V3{rcn.ix, rcn.iy, rcn.iz});
             if (best.ref != before) best.cls = (cur & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
             cur = sp ? trav_pop<SPILL, STRIDE>(mem, sp) : RT_REF_NONE;
         }
     } while (more(uint32_t(__popcll(__ballot(cur != RT_REF_NONE))), uint32_t(__popcll(__ballot(cur == RT_REF_NONE)))));
     return rounds;
+}
+
+// The primitives the upload kept out of the wide tree because they enclose the rest of the scene
+// (DScene::post_ref): tested against the closest hit the walk found, by all lanes whose walk has ended
+// at once -- inside the walk each lane would get to them at a moment of its own.  The closest hit does
+// not depend on the order of the tests (a medium's draw is keyed by the ray, not by the order).
+__device__ __forceinline__ void test_post(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref, const RayCtx &rc, Best &best) {
+    const uint32_t n = sc.n_post; // uniform
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t word = sc.post_ref[i], before = best.ref;
+        test_prim<true>(sc, word & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best);
+        if (best.ref != before) best.cls = (word & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
+    }
 }
 
 template <bool STAGED, bool QUANT>
@@ -718,6 +787,7 @@ __device__ __forceinline__ void traverse4(SceneRef sc, V3 o, V3 d, float time, f
     const TravMem mem = block_trav_mem(sc, s_dyn, QUANT ? 64u : 128u);
     // until every lane of the wave is done
     trav4_rounds<STAGED, QUANT>(sc, o, d, time, tlo, origin_ref, rc, mem, cur, sp, best, [](uint32_t n_trav, uint32_t) { return n_trav != 0; });
+    test_post(sc, o, d, time, tlo, origin_ref, rc, best);
 }
 
 // One entry for the three structures.  s_stack / s_nodes: static LDS of the binary traversal;
@@ -1373,7 +1443,11 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
         if (TABLES) m = tb.mats[mat_id];
         else m = sc.mats[mat_id];
         if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
-        if (kind == RT_KIND_QUAD && quad_uv_missing && m.needs_uv) quad_uv(sc.quads + 6 * idx, p, u, v);
+        // (a face of a box leaf of the wide tree comes without its (alpha, beta) too: NaN)
+        if (kind == RT_KIND_QUAD && m.needs_uv) {
+            if (quad_uv_missing) quad_uv(sc.quads + 6 * idx, p, u, v);
+            else if (u != u) quad_uv_ray(sc.quads + 6 * idx, o, d, h.x, u, v);
+        }
         if (DEPOSIT && m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
             // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
             if (front) deposit = m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p);
@@ -1599,11 +1673,14 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
     // wide BVH, per wave: 0 node steps, 1 primitive steps, 2 shading passes (lanes with a hit to look at),
     // 3 lanes that scatter, 4 lanes that take a new sample, 5 calls for traversal rounds (lanes traversing)
     TravStats ts;
-    unsigned long long pk_turns[RG_STATS] = {}, pk_lanes[RG_STATS] = {};
+    unsigned long long pk_turns[RG_STATS] = {}, pk_lanes[RG_STATS] = {}, pk_ticks[RG_STATS] = {};
+    unsigned long long pk_t0 = wall_clock64();
 #define RT_PK_COUNT(i, m) (pk_turns[i] += 1, pk_lanes[i] += (m))
+#define RT_PK_TICK(i) { const unsigned long long now_ = wall_clock64(); pk_ticks[i] += now_ - pk_t0; pk_t0 = now_; }
 #define RT_PK_TS , &ts
 #else
 #define RT_PK_COUNT(i, m) ((void)0)
+#define RT_PK_TICK(i) ((void)0)
 #define RT_PK_TS
 #endif
     for (;;) {
@@ -1628,14 +1705,21 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                         trav4_rounds<false, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
                 }
                 RT_PK_COUNT(5, n_busy);
+                RT_PK_TICK(5);
                 continue;
             }
             if (__ballot(alive) == 0 && exhausted) break;
             RT_PK_COUNT(2, uint32_t(__popcll(__ballot(alive && !busy))));
-            if (alive && !busy)
+            if (alive && !busy) {
+                if (sc.n_post) { // uniform
+                    RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
+                    test_post(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, best);
+                }
                 scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
                                      false, sf);
+            }
             RT_PK_COUNT(3, uint32_t(__popcll(__ballot(scatter))));
+            RT_PK_TICK(2); // post tests and what the hit itself contributes
         } else {
             // 1. closest hit, then what the hit itself contributes (background, emission)
             const unsigned long long live = __ballot(alive);
@@ -1691,6 +1775,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         Rng rng;
         rng.begin(k0, k1, fbits(sa.w), sb.x, fresh ? STREAM_CAMERA : STREAM_SHADE, sb.y);
         RT_PK_COUNT(4, uint32_t(__popcll(__ballot(fresh))));
+        RT_PK_TICK(6); // new samples taken, one Philox block
         if (fresh) {
             V3 o, d;
             float time;
@@ -1699,11 +1784,18 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
             rb = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
             sa = make_float4(1.f, 1.f, 1.f, sa.w);
             alive = true;
-        } else if (scatter) {
+        }
+#ifdef RT_REGROUP_STATS // (the product build keeps one if / else chain: split like this it compiles 8 % slower)
+        RT_PK_TICK(4); // camera rays
+        if (!fresh && scatter) {
+#else
+        else if (scatter) {
+#endif
             alive = shade_scatter<MODE>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
-        } else if (!busy) {
+        } else if (!fresh && !busy) {
             alive = false;
         }
+        RT_PK_TICK(3); // scatter
         if constexpr (accel_is_wide(ACCEL)) { // lanes with a new ray start its traversal
             const bool start = alive && !busy;
             n_seg += uint32_t(__popcll(__ballot(start)));
@@ -1715,10 +1807,12 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         atomicAdd(&ctrl->camera_rays, n_cam);
 #ifdef RT_REGROUP_STATS
         pk_turns[0] = ts.node_steps, pk_lanes[0] = ts.node_lanes, pk_turns[1] = ts.prim_steps, pk_lanes[1] = ts.prim_lanes;
-        for (uint32_t i = 0; i < RG_STATS; ++i) atomicAdd(&g_rg_stats[i], pk_turns[i]), atomicAdd(&g_rg_stats[RG_STATS + i], pk_lanes[i]);
+        for (uint32_t i = 0; i < RG_STATS; ++i)
+            atomicAdd(&g_rg_stats[i], pk_turns[i]), atomicAdd(&g_rg_stats[RG_STATS + i], pk_lanes[i]), atomicAdd(&g_rg_stats[2 * RG_STATS + i], pk_ticks[i]);
 #endif
     }
 #undef RT_PK_COUNT
+#undef RT_PK_TICK
 #undef RT_PK_TS
 }
 
@@ -2207,6 +2301,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
             const bool done = busy && cur == RT_REF_NONE;
             uint32_t kind = RG_LISTS;
             if (done) {
+                if (sc.n_post) test_post(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, best); // uniform
                 const V3 p = fma3(mk(rb), best.t, mk(ra)); // as shade_emit forms it
                 pool.ra[slot] = make_float4(p.x, p.y, p.z, ra.w);
                 pool.rb[slot].w = bitsf(best.ref); // the direction is still there
@@ -2357,6 +2452,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect_batch(const DScene *scp, ui
         if (kind == RT_KIND_QUAD) {
             pid = int(fbits(sc.quads[6 * idx + 4].w));
             if (ACCEL == ACCEL_FLAT) quad_uv(sc.quads + 6 * idx, fma3(d, best.t, o), uu, vv);
+            else if (uu != uu) quad_uv_ray(sc.quads + 6 * idx, o, d, best.t, uu, vv);
         } else if (kind == RT_KIND_SPHERE) {
             const float4 *S = sc.spheres + 3 * idx;
             float4 s0 = S[0], s1 = S[1], s2 = S[2];

@@ -12,3 +12,9 @@
 #define RT4_CLASS_GLASS 2u
 #define RT4_CLASS_END 3u     /* DiffuseLight: the path ends there */
 
+
+// A kind of leaf only the wide BVH has (the descriptor's references stop at RT_KIND_MEDIUM): six
+// parallelograms of one list that are the faces of a box along the world's axes -- what box3 builds
+// (hittable.rs:398-455) -- searched as one leaf with one slab test.  The index is into the box
+// records the upload derives (rt_accel.h, WideBox); a hit is reported on the face's own quad.
+#define RT_KIND_BOX 4u
