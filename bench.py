@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--regroup", choices=["auto", "on", "off"], default="auto",
                     help="persistent kernel on a flat world: paths regrouped per wave by the step they wait for, or lane-bound")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="process-group backend (default: nccl = RCCL)")
+    ap.add_argument("--reduce", default="torch", choices=["torch", "c-abi"],
+                    help="the film all-reduce: torch.distributed's (RCCL under the nccl backend), or the library's own rt_film_allreduce "
+                         "(RCCL inside librt_amd.so, what a host without Python calls)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU machine: every rank uses GPU 0 (needs --backend gloo); the line is marked")
     args = ap.parse_args()
@@ -163,7 +166,7 @@ def main():
     dev.upload(sb)
     rcam = cam.build()
     n_strata = cam.effective_spp
-    renderer = rdist.DistributedRenderer(dev, local)
+    renderer = rdist.DistributedRenderer(dev, local, reduce=args.reduce)
     renderer.bind_film(cam.image_width, cam.image_height)
 
     def barrier():
@@ -199,7 +202,8 @@ def main():
         # kernels are bracketed by HIP events on the stream they run on: the one launch of the
         # persistent kernel, or every 8th wavefront iteration (rotating from step to step; an
         # event is a barrier packet on the stream, timing all of them costs ~10 %)
-        _, st = renderer.render(rcam, n_strata, rank, world, mode, seed=1 + step, time_kernels=True, **extra)
+        # (two films in turn: a frame's all-reduce is in flight while the next frame is rendered)
+        _, st = renderer.render_async(rcam, n_strata, rank, world, mode, seed=1 + step, time_kernels=True, **extra)
         if st is not None:
             seg += st.segments
             cam_rays += st.camera_rays
@@ -208,6 +212,7 @@ def main():
             timed += np.array(st.timed_launches)
             launches += np.array(st.launches)
         note(f"step {step + 1} of {args.steps} done")
+    renderer.wait()  # the last frames' reduces
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -245,7 +250,8 @@ def main():
         "config": {"workload": desc, "name": args.workload, "image": [cam.image_width, cam.image_height],
                    "spp": n_strata, "max_depth": cam.max_depth, "estimator": "book3" if mode == ra.RT_MODE_BOOK3 else "ref-exact",
                    "pipeline": "wavefront" if args.wavefront else ("persistent, paths regrouped per wave" if regrouped else "persistent"),
-                   "parallelism": f"spp-split x{world}, one fp32 film all-reduce per step",
+                   "parallelism": f"spp-split x{world}, one fp32 film all-reduce per step ({'rt_film_allreduce, C ABI' if args.reduce == 'c-abi' else 'torch.distributed'}), "
+                                  "two films in turn",
                    "segments_per_step": int(total_seg / args.steps), "segments_per_camera_ray": round(total_seg / max(total_cam, 1), 3)},
         "time_to_1000spp_s": round(ms_per_step * 1e-3 * 1000.0 / n_strata, 4),
         "kernel_ms_per_step": {n: round(float(per_launch_ms[i] * launches[i]) / args.steps, 3) for i, n in enumerate(names)},

@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def main(out_dir, scene, width, spp, seeds, backend="gloo"):
+def main(out_dir, scene, width, spp, seeds, backend="gloo", reduce="torch"):
     import torch
     import torch.distributed as dist
     import raytracing_amd as ra
@@ -26,11 +26,18 @@ def main(out_dir, scene, width, spp, seeds, backend="gloo"):
     cam = getattr(ra.scenes, scene)(sb, width=width, spp=spp)
     dev = ra.Device(0)
     dev.upload(sb)
-    renderer = rdist.DistributedRenderer(dev, 0)
+    renderer = rdist.DistributedRenderer(dev, 0, reduce=reduce)
     rcam = cam.build()
     mode = ra.RT_MODE_REF_EXACT if scene == "cornell_main" else ra.RT_MODE_BOOK3
-    for seed in seeds:  # consecutive frames into the same film: clear, render and reduce must stay ordered
+    # consecutive frames into two films in turn, none waited for before the next is rendered: clear, render
+    # and reduce of every film must stay ordered, and a film must not be cleared under its own reduce
+    frames = [renderer.render_async(rcam, cam.effective_spp, rank, world, mode, seed=seed) for seed in seeds[:2]]
+    renderer.wait()
+    kept = [(f.clone(), st) for f, st in frames]
+    for seed in seeds[2:]:
         film, st = renderer.render(rcam, cam.effective_spp, rank, world, mode, seed=seed)
+        kept.append((film.clone(), st))
+    for seed, (film, st) in zip(seeds, kept):
         seg = torch.tensor([float(st.segments if st else 0), float(st.camera_rays if st else 0)], dtype=torch.float64,
                            device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(seg)
@@ -45,4 +52,4 @@ def main(out_dir, scene, width, spp, seeds, backend="gloo"):
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), [int(s) for s in sys.argv[5].split(",")],
-         *(sys.argv[6:7]))
+         *(sys.argv[6:8]))

@@ -13,16 +13,19 @@ ROOT = Path(__file__).resolve().parent.parent
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("scene,world,backend", [("cornell_book3", 2, "gloo"), ("cornell_main", 3, "gloo"), ("cornell_book3", 1, "nccl")])
-def test_ranks_sharing_gpu0_reproduce_the_one_rank_render(tmp_path, scene, world, backend):
-    """(The last case is one rank with a process group over RCCL: clear, render and the all-reduce
-    of the film run on the renderer's stream through the backend the 8-GPU job uses.)"""
+@pytest.mark.parametrize("scene,world,backend,reduce", [("cornell_book3", 2, "gloo", "torch"), ("cornell_main", 3, "gloo", "torch"),
+                                                        ("cornell_book3", 1, "nccl", "torch"), ("cornell_book3", 1, "nccl", "c-abi")])
+def test_ranks_sharing_gpu0_reproduce_the_one_rank_render(tmp_path, scene, world, backend, reduce):
+    """(The last two cases are one rank with a process group over RCCL: clear, render and the all-reduce
+    of the film through the backend the 8-GPU job uses -- torch.distributed's all_reduce, enqueued
+    without waiting while the next frame renders into the other film, and the library's own
+    rt_film_allreduce with the group's id handed over through the process group.)"""
     import raytracing_amd as ra
     from raytracing_amd import distributed as rdist
     seeds = [5, 6, 7]
     width, spp = 96, 25  # 25 strata do not divide evenly over 2 or 3 ranks
     rc = rdist.spawn_ranks([sys.executable, str(ROOT / "tests" / "dist_worker.py"), str(tmp_path), scene, str(width), str(spp),
-                            ",".join(map(str, seeds)), backend], world, share_gpu=True)
+                            ",".join(map(str, seeds)), backend, reduce], world, share_gpu=True, timeout=500)
     assert rc == 0
     sb = ra.SceneBuilder()
     cam = getattr(ra.scenes, scene)(sb, width=width, spp=spp)

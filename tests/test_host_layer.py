@@ -870,3 +870,19 @@ def test_spawn_ranks_sets_the_launcher_environment_and_reports_failures(tmp_path
     t0 = time.time()
     rc = rdist.spawn_ranks([sys.executable, "-c", "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(60)"], 3)
     assert rc == 7 and time.time() - t0 < 30
+    # no rank fails, one never finishes (a collective that does not complete): the deadline ends the job
+    t0 = time.time()
+    rc = rdist.spawn_ranks([sys.executable, "-c", "import os, time; time.sleep(0 if os.environ['RANK'] == '0' else 60)"], 2, timeout=2.0)
+    assert rc == 124 and time.time() - t0 < 20
+
+
+def test_film_rgb8_rejects_a_wrong_destination_without_asserting():
+    """The destination of film_rgb8 is checked with an exception, not an assert that python -O strips: a
+    short buffer would be a heap overwrite in native code."""
+    class FakeDevice(ra.Device):
+        def __init__(self):  # no GPU needed to reach the check
+            self.h, self.width, self.height = None, 4, 4
+    dev = FakeDevice()
+    for bad in (np.zeros(47, np.uint8), np.zeros(48, np.float32), np.zeros((4, 4, 6), np.uint8)[:, :, ::2], [0] * 48):
+        with pytest.raises(ValueError, match="48 bytes"):
+            dev.film_rgb8(1.0, out=bad)
