@@ -1,6 +1,6 @@
 // main.cpp -- the counterpart of the reference's binary (main.rs:12-72) on the device backend.
 //
-//   rt_main [--config cornell_box.toml] [--out image.png] [--spp 20] [--width 600] [--seed 1]
+//   rt_main [--config cornell_box.toml] [--out image.png] [--spp 20] [--width 600] [--seed 1] [--gpus N]
 //   rt_main --scene scenes/book1_final/book1_final.toml [--out image.png] [--spp N] [--width W]
 //           [--height H] [--mode ref-exact|book3] [--ppm]
 //
@@ -8,6 +8,8 @@
 // quad and the two rotated boxes added in code, with the shipped estimator.  With --scene the
 // file describes the whole render (camera, lights, instances); the mixture estimator is the
 // default there because most such scenes hold materials the shipped one cannot scatter.
+// --gpus N splits the strata over GPUs 0 .. N-1 of this process and sums the films with
+// rt_film_allreduce (RCCL); --device picks the GPU of a one-GPU render.
 #include "raytracing.hpp"
 
 #include <cmath>
@@ -38,7 +40,7 @@ double radians(double deg) { return deg * M_PI / 180.0; }
 
 struct Args {
     std::string config = "cornell_box.toml", scene, out = "image.png";
-    long spp = -1, width = -1, height = -1, device = 0;
+    long spp = -1, width = -1, height = -1, device = 0, gpus = 1;
     unsigned long long seed = 1;
     int mode = -1;
     bool ppm = false;
@@ -59,6 +61,7 @@ Args parse(int argc, char **argv) {
         else if (k == "--width") a.width = std::atol(val());
         else if (k == "--height") a.height = std::atol(val());
         else if (k == "--device") a.device = std::atol(val());
+        else if (k == "--gpus") a.gpus = std::atol(val());
         else if (k == "--seed") a.seed = std::strtoull(val(), nullptr, 10);
         else if (k == "--ppm") a.ppm = true;
         else if (k == "--mode") {
@@ -83,6 +86,9 @@ int main(int argc, char **argv) {
         RenderSettings rs;
         rs.device_id = int(a.device);
         rs.seed = a.seed;
+        if (a.gpus < 1 || a.gpus > 64) throw Error("--gpus takes 1 to 64");
+        if (a.gpus > 1)
+            for (long g = 0; g < a.gpus; ++g) rs.devices.push_back(int(g));
         if (a.scene.empty()) {
             // main.rs:15-26
             cb.with_aspect_ratio(600, 1.0)

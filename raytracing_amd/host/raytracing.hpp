@@ -346,6 +346,10 @@ class PngWriter : public ImageWriter { // export.rs:43-86: 8-bit RGB, linear val
 // estimator (the shipped one by default), and the seed the reference draws from the OS.
 struct RenderSettings {
     int device_id = 0;
+    // More than one entry: the frame's strata (camera.rs:390-395) are split over these GPUs, every one
+    // renders the full frame for its own range, and the films are summed by rt_film_allreduce (RCCL);
+    // device_id is then ignored.  One process, one handle and one host thread per GPU.
+    std::vector<int> devices;
     uint32_t mode = RT_MODE_REF_EXACT;
     uint32_t flags = 0; // RT_FLAG_*
     uint64_t seed = 1;

@@ -740,6 +740,61 @@ def test_box_leaves_of_the_wide_tree_take_the_six_quads_answers(device):
         assert r["median_rel"] < 1.5e-7 and r["frac_5e2"] < FORKED, (pipeline, r)
 
 
+def test_byte_boxes_hold_for_rays_from_far_away(device):
+    """The 64-byte nodes store child boxes as bytes on a grid, widened by a few fp32 ulps of the NODE's
+    coordinates; the device evaluates q * (s / d) + (origin - o) / d in fp32, whose rounding error grows
+    with the ray's distance |origin - o| to the node, not with the node's coordinates.  Small thin quads
+    and spheres about the world's origin, rays that start 1e3 to 1e4 scene extents away and are aimed
+    at them: byte boxes must report what fp32 boxes report (a box entered needlessly costs time, a box
+    missed would lose the hit), and both what the oracle reports."""
+    def build(sb):
+        rng = np.random.Generator(np.random.Philox(key=4242))
+        white = sb.lambertian(sb.tex_solid(0.7, 0.7, 0.7))
+        objs = []
+        for k in range(400):
+            c = rng.random(3) * 2.0 - 1.0
+            axis = k % 3
+            u, v = np.zeros(3), np.zeros(3)
+            u[(axis + 1) % 3], v[(axis + 2) % 3] = 0.02 + 0.05 * rng.random(), 0.02 + 0.05 * rng.random()
+            objs.append(sb.quad(tuple(c), tuple(u), tuple(v), white))  # axis-aligned: boxes 1e-4 thick
+        for k in range(200):
+            objs.append(sb.sphere(tuple(rng.random(3) * 2.0 - 1.0), 0.01 + 0.02 * rng.random(), white))
+        sb.set_world(sb.list([sb.bvh(objs)]))
+        sb.set_lights(None)
+    host, osb = ra.SceneBuilder(), orc.scene()
+    build(host), build(osb)
+    rng = np.random.default_rng(12)
+    n = 40000
+    target = (rng.random((n, 3)) * 2.0 - 1.0)
+    away = rng.standard_normal((n, 3))
+    away /= np.linalg.norm(away, axis=1, keepdims=True)
+    dist = 10.0 ** rng.uniform(3.3, 4.3, (n, 1))  # 2e3 .. 2e4 = 1e3 .. 1e4 extents of the 2-unit scene
+    o = (target + away * dist).astype(np.float32)
+    d = (target - o.astype(np.float64)).astype(np.float32)
+    tm = np.zeros(n, np.float32)
+    res = {}
+    try:
+        for name, fp32 in (("fp32", True), ("bytes", False)):
+            for builder in ("reference", "sah"):
+                device.set_accel(builder, 4, fp32_boxes=fp32)
+                device.upload(host)
+                assert device.accel_info()["node_bytes"] == (128 if fp32 else 64)
+                res[name, builder] = device.intersect_batch(o, d, tm)
+    finally:
+        device.set_accel("auto", 4)
+    for builder in ("reference", "sah"):
+        (h0, p0, t0, _, _), (h1, p1, t1, _, _) = res["fp32", builder], res["bytes", builder]
+        assert 0.05 < h0.mean() < 0.9
+        assert np.array_equal(h0, h1) and np.array_equal(p0, p1) and np.array_equal(t0, t1)
+    h0, p0, t0, _, _ = res["bytes", "sah"]
+    h2, p2, t2, _, _, second = orc.intersect_batch(osb, o, d, tm)
+    # from 1e4 away fp32 places a ray to 1e-3 of the scene: the oracle, fed the same fp32 rays, decides edge
+    # cases otherwise; a primitive hit by both is hit at the same distance to fp32's resolution there
+    both = (h0 == 1) & (h2 == 1) & (p0 == p2)
+    assert ((h0 != h2) | (p0 != p2)).mean() < 0.02 and both.mean() > 0.05
+    assert np.quantile(np.abs(t0[both] - t2[both]) / t2[both], 0.99) < 1e-5
+
+
 def test_rectangles_along_the_world_axes_take_the_quad_tests_answers(device):
     """Rectangles whose normal and edges run along the world's axes (a lamp under a ceiling, a floor)
     leave a flat world's quad records for a test without dot products.  It is the quad test's own
@@ -1248,6 +1303,19 @@ def test_native_binary_writes_the_same_bytes_as_the_python_route(device, tmp_pat
     assert tok[:4] == ["P3", "48", "48", "255"]
     got = np.array(tok[4:], dtype=np.uint8).reshape(48, 48, 3)
     _same_bytes_up_to_summation_order(got, want)
+    # --gpus N splits the strata over N GPUs of the process and sums the films through rt_film_allreduce;
+    # on a machine with fewer GPUs it says so instead of rendering a part (--gpus 1 is the plain render)
+    n_gpus = ra.device_count()
+    r = subprocess.run([str(exe), "--config", str(root / "scenes" / "cornell_box.toml"), "--width", "32", "--spp", "4", "--gpus", str(n_gpus + 1),
+                        "--out", str(tmp_path / "none.png")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "rt_create" in r.stderr and not (tmp_path / "none.png").exists(), r.stderr
+    if n_gpus >= 2:  # (the driver's eight-GPU node: the same frame on two GPUs)
+        r = subprocess.run([str(exe), "--config", str(root / "scenes" / "cornell_box.toml"), "--width", "64", "--spp", "16", "--seed", "3",
+                            "--gpus", "2", "--out", str(tmp_path / "two.png")], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        two = ra.imageio.read_png(tmp_path / "two.png")
+        one = ra.imageio.read_png(out)
+        _same_bytes_up_to_summation_order(two, one)
 
 
 DISC_TOML = '''
