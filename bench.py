@@ -59,7 +59,7 @@ FILM_BYTES_PER_PATH = 24         # three fp32 read-modify-writes when a path dep
 # (c2, c4, c5: full scene content, a few strata of the full frame, the reference's own binary BVH
 # walked left child first -- 40.9, 12.2 and 340.8 box tests per segment).  Averaged over the
 # segments that carry weight, the ones the device traces (see live_segments).
-FLOPS_PER_SEGMENT = {"c3": 499.4, "c1": 681.4, "c2": 1310.7, "c4": 934.4, "c5": 9528.7}
+FLOPS_PER_SEGMENT = {"c3": 559.1, "c1": 681.4, "c2": 1310.7, "c4": 1162.7, "c5": 9528.7}
 # Counter digests of the dominant kernel per workload, made from rocprofv3 PMC passes of this
 # binary by tools/pmc_to_bench.py (counters need runs of their own: FETCH_SIZE and WRITE_SIZE do
 # not fit one pass).  Each entry names the summary under profiles/ it was made from.
@@ -72,7 +72,7 @@ def pmc_digest(workload, kernel):
         entry = json.loads(PMC_DIGEST.read_text()).get(workload)
     except (OSError, ValueError):
         return None
-    return entry if entry and entry.get("kernel", "").startswith(kernel) else None
+    return entry if entry and entry.get("kernel", "") == kernel else None
 
 
 def live_segments(cnt):

@@ -454,10 +454,10 @@ void drain_timers(rt_handle *h, size_t upto) {
 void drain_timers(rt_handle *h) { drain_timers(h, h->ev_used); }
 
 // One launch of the persistent path kernel: as many blocks as the device keeps resident.
-template <int MODE, int ACCEL>
+template <int MODE, int ACCEL, bool EXTRAS = true>
 int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
                  unsigned long long total) {
-    auto kernel = k_paths<MODE, ACCEL>;
+    auto kernel = k_paths<MODE, ACCEL, EXTRAS>;
     int per_cu = 0, n_cu = 0;
     const size_t dyn_lds = accel_is_wide(ACCEL) ? h->dyn_lds4() : 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));
@@ -517,9 +517,9 @@ int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &fi
 
 // The regrouping kernel behind the wide BVH: a pool of paths per wave, traversals resumable per lane.
 constexpr uint32_t POOL_MIN_NODES = 8192; // trees from this size take it by default
-template <int MODE, bool QUANT>
+template <int MODE, bool QUANT, bool EXTRAS>
 int launch_paths_pool(rt_handle *h, const rt_render_params *p, const Film &film, unsigned long long total) {
-    auto kernel = k_paths_pool<MODE, QUANT>;
+    auto kernel = k_paths_pool<MODE, QUANT, EXTRAS>;
     // what is left of a quarter of the CU's LDS behind pools and stacks holds the top of the tree
     const size_t node_bytes = QUANT ? sizeof(Node4Q) : sizeof(Node4), budget = 40 * 1024;
     const uint32_t lds_nodes = POOL_LDS_FIXED < budget ? uint32_t(std::min<size_t>(h->accel_stats.nodes, (budget - POOL_LDS_FIXED) / node_bytes)) : 0u;
@@ -560,6 +560,9 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     // the regrouping kernel packs stratum and bounce into one word
     const bool regroup_fits = uint64_t(dc.sqrt_spp) * dc.sqrt_spp <= REGROUP_MAX_STRATA && dc.max_depth <= REGROUP_MAX_DEPTH;
     const bool regroup_wanted = !(p->flags & RT_FLAG_NO_REGROUP);
+    // box leaves in the wide tree, or primitives kept out of it and tested after the walk: the kernels
+    // behind a tree are compiled with and without the code for them
+    const bool extras = h->n_box_leaves != 0 || h->sc.n_post != 0;
     if (h->accel == ACCEL_FLAT && regroup_wanted && regroup_fits) {
         // a small scene's quads, spheres and materials are copied into LDS tables
         const bool tables = h->n_quads <= TABLE_QUADS && h->n_spheres <= TABLE_SPHERES && h->n_materials <= TABLE_MATERIALS;
@@ -571,15 +574,16 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
                ((p->flags & RT_FLAG_REGROUP) || (regroup_wanted && h->accel_stats.nodes >= POOL_MIN_NODES))) {
         // behind a tree the pool of paths per wave pays where traversals are long (measured: +14 % at 466 k
         // nodes, -2 % at 232); RT_FLAG_REGROUP asks for it on any tree
-        if (p->mode == RT_MODE_REF_EXACT)
-            rc = h->accel == ACCEL_BVH4Q ? launch_paths_pool<RT_MODE_REF_EXACT, true>(h, p, film, total) : launch_paths_pool<RT_MODE_REF_EXACT, false>(h, p, film, total);
-        else
-            rc = h->accel == ACCEL_BVH4Q ? launch_paths_pool<RT_MODE_BOOK3, true>(h, p, film, total) : launch_paths_pool<RT_MODE_BOOK3, false>(h, p, film, total);
+#define RT_POOL(MODE)                                                                                                        \
+    (h->accel == ACCEL_BVH4Q ? (extras ? launch_paths_pool<MODE, true, true>(h, p, film, total) : launch_paths_pool<MODE, true, false>(h, p, film, total)) \
+                             : (extras ? launch_paths_pool<MODE, false, true>(h, p, film, total) : launch_paths_pool<MODE, false, false>(h, p, film, total)))
+        rc = p->mode == RT_MODE_REF_EXACT ? RT_POOL(RT_MODE_REF_EXACT) : RT_POOL(RT_MODE_BOOK3);
+#undef RT_POOL
     } else {
 #define RT_PATHS(MODE)                                                                                    \
     (h->accel == ACCEL_FLAT   ? launch_paths<MODE, ACCEL_FLAT>(h, dc, p, film, total)                        \
-     : h->accel == ACCEL_BVH4 ? launch_paths<MODE, ACCEL_BVH4>(h, dc, p, film, total)                        \
-     : h->accel == ACCEL_BVH4Q ? launch_paths<MODE, ACCEL_BVH4Q>(h, dc, p, film, total)                      \
+     : h->accel == ACCEL_BVH4 ? (extras ? launch_paths<MODE, ACCEL_BVH4, true>(h, dc, p, film, total) : launch_paths<MODE, ACCEL_BVH4, false>(h, dc, p, film, total))    \
+     : h->accel == ACCEL_BVH4Q ? (extras ? launch_paths<MODE, ACCEL_BVH4Q, true>(h, dc, p, film, total) : launch_paths<MODE, ACCEL_BVH4Q, false>(h, dc, p, film, total)) \
                               : launch_paths<MODE, ACCEL_BVH2>(h, dc, p, film, total))
     rc = p->mode == RT_MODE_REF_EXACT ? RT_PATHS(RT_MODE_REF_EXACT) : RT_PATHS(RT_MODE_BOOK3);
 #undef RT_PATHS

@@ -407,13 +407,15 @@ __device__ __forceinline__ bool hit_wide_box(const float4 *__restrict__ B, V3 o,
     return true;
 }
 
-template <bool UNIFORM = false>
+// EXTRAS: the tree may hold box leaves (false compiles their test out: the kernels behind a tree sit at
+// their register limit, and a scene without such leaves ran 3 % slower with the test compiled in).
+template <bool UNIFORM = false, bool EXTRAS = true>
 __device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, float time, float tlo,
                                           uint32_t origin_ref, const RayCtx &rc, Best &best, V3 inv = V3{0.f, 0.f, 0.f}) {
     uint32_t kind = r >> RT_REF_KIND_SHIFT, idx = r & RT_REF_INDEX_MASK;
     float t, a = 0.f, b = 0.f;
     bool h;
-    if (kind == RT_KIND_BOX) { // wide tree only (the caller passes inv = 1/d)
+    if (EXTRAS && kind == RT_KIND_BOX) { // wide tree only (the caller passes inv = 1/d)
         uint32_t face = RT_REF_NONE;
         h = hit_wide_box(sc.wide_boxes + 3 * idx, o, d, inv, tlo, best.t, origin_ref, t, face);
         // between coincident faces of two boxes the later quad wins, as between two quads (below)
@@ -685,7 +687,7 @@ key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                           
 // says no (asked after every round, wave-uniform; both counts are of the calling lanes).  The
 // per-ray constants are made once per call: a caller that came back for every round paid for them
 // -- three reciprocals and the plane offsets -- once per primitive test.  Returns the rounds run.
-template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK, typename More>
+template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK, bool EXTRAS = true, typename More>
 __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
                                                  const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best,
                                                  More more, TravStats *ts = nullptr) {
@@ -758,7 +760,7 @@ __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float 
         if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
             // a leaf's word carries the class of its material above the index (rt_accel.h)
             const uint32_t before = best.ref;
-            test_prim(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best, V3{rcn.ix, rcn.iy, rcn.iz});
+            test_prim<false, EXTRAS>(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best, V3{rcn.ix, rcn.iy, rcn.iz});
             if (best.ref != before) best.cls = (cur & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
             cur = sp ? trav_pop<SPILL, STRIDE>(mem, sp) : RT_REF_NONE;
         }
@@ -1383,7 +1385,7 @@ struct Surface {
 // through its loop; they are recomputed here for the materials that look at them.
 // DEPOSIT = false: the caller knows the hit is a surface that scatters (k_paths_regroup's scatter
 // steps); only `sf` is wanted.  TABLES: quads, spheres and materials come from `tb`.
-template <bool DEPOSIT = true, bool TABLES = false>
+template <bool DEPOSIT = true, bool TABLES = false, bool EXTRAS = true>
 __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &film, const float4 &ra,
                                            const float4 &rb, const float4 &sa, float4 h, bool quad_uv_missing,
                                            Surface &sf, const FlatTables &tb = FlatTables{}) {
@@ -1446,7 +1448,7 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
         // (a face of a box leaf of the wide tree comes without its (alpha, beta) too: NaN)
         if (kind == RT_KIND_QUAD && m.needs_uv) {
             if (quad_uv_missing) quad_uv(sc.quads + 6 * idx, p, u, v);
-            else if (u != u) quad_uv_ray(sc.quads + 6 * idx, o, d, h.x, u, v);
+            else if (EXTRAS && u != u) quad_uv_ray(sc.quads + 6 * idx, o, d, h.x, u, v);
         }
         if (DEPOSIT && m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
             // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
@@ -1637,7 +1639,8 @@ __device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
 
 // Registers are held to 128 per lane (4 waves per SIMD): measured faster than 3 waves with no
 // spills or 5, 6, 8 with more, on every workload, flat and BVH.
-template <int MODE, int ACCEL>
+// EXTRAS (wide tree): the scene has box leaves or primitives tested after the walk.
+template <int MODE, int ACCEL, bool EXTRAS = true>
 __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
                                                   uint32_t has_media, uint32_t grab, uint32_t refill_min) {
     SceneRef sc = *as_uniform(scp);
@@ -1700,9 +1703,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                     // rounds until the lanes that finish bring the shading steps their quorum
                     auto more = [&](uint32_t n_trav, uint32_t n_fin) { return n_trav != 0 && n_work + n_fin < SHADE_QUORUM; };
                     if (sc.lds_nodes4) // uniform
-                        trav4_rounds<true, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
+                        trav4_rounds<true, ACCEL == ACCEL_BVH4Q, false, BLOCK, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
                     else
-                        trav4_rounds<false, ACCEL == ACCEL_BVH4Q>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
+                        trav4_rounds<false, ACCEL == ACCEL_BVH4Q, false, BLOCK, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
                 }
                 RT_PK_COUNT(5, n_busy);
                 RT_PK_TICK(5);
@@ -1711,12 +1714,12 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
             if (__ballot(alive) == 0 && exhausted) break;
             RT_PK_COUNT(2, uint32_t(__popcll(__ballot(alive && !busy))));
             if (alive && !busy) {
-                if (sc.n_post) { // uniform
+                if (EXTRAS && sc.n_post) { // uniform
                     RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
                     test_post(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, best);
                 }
-                scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
-                                     false, sf);
+                scatter = shade_emit<true, false, EXTRAS>(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
+                                                          false, sf);
             }
             RT_PK_COUNT(3, uint32_t(__popcll(__ballot(scatter))));
             RT_PK_TICK(2); // post tests and what the hit itself contributes
@@ -1728,8 +1731,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
             if (alive) {
                 RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
                 closest_hit<ACCEL, true>(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, s_stack, s_nodes, s_dyn, best);
-                scatter = shade_emit(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
-                                     ACCEL == ACCEL_FLAT, sf);
+                scatter = shade_emit<true, false, false>(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
+                                                         ACCEL == ACCEL_FLAT, sf);
             }
         }
         // 2. idle lanes take new samples
@@ -2189,7 +2192,7 @@ static_assert(POOL_SLOTS <= 256 && POOL_SLOTS >= WAVE && POOL_SLOTS % 8 == 0, "s
 // dynamic LDS of a block: the pools, then [POOL_STACK][WAVE] stack words per wave, then the staged nodes
 constexpr size_t POOL_LDS_FIXED = (BLOCK / WAVE) * (sizeof(TravPool) + size_t(POOL_STACK) * WAVE * sizeof(uint32_t));
 
-template <int MODE, bool QUANT>
+template <int MODE, bool QUANT, bool EXTRAS = true>
 __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1,
                                                         Ctrl *ctrl, uint32_t has_media, uint32_t grab, uint32_t *spill,
                                                         uint32_t lds_nodes) {
@@ -2300,9 +2303,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
                 // costs more than the per-ray constants made again for every round (measured: -12 %)
                 auto more = [](uint32_t, uint32_t) { return false; };
                 if (lds_nodes) // uniform
-                    rounds = trav4_rounds<true, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
+                    rounds = trav4_rounds<true, QUANT, true, WAVE, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
                 else
-                    rounds = trav4_rounds<false, QUANT, true, WAVE>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
+                    rounds = trav4_rounds<false, QUANT, true, WAVE, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
             }
             (void)rounds;
             RT_RG_COUNT(RG_RAY, n_trav);
@@ -2314,7 +2317,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
             const bool done = busy && cur == RT_REF_NONE;
             uint32_t kind = RG_LISTS;
             if (done) {
-                if (sc.n_post) test_post(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, best); // uniform
+                if (EXTRAS && sc.n_post) test_post(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, best); // uniform
                 const V3 p = fma3(mk(rb), best.t, mk(ra)); // as shade_emit forms it
                 pool.ra[slot] = make_float4(p.x, p.y, p.z, ra.w);
                 pool.rb[slot].w = bitsf(best.ref); // the direction is still there

@@ -19,3 +19,5 @@ echo "c4 done"
 timeout -k 10 300 python3 bench.py --wavefront --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_c3_wavefront.json" 2> "$OUT/${TAG}_bench_c3_wavefront.err" || exit 1
 timeout -k 10 300 python3 bench.py --regroup off --steps 10 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_c3_lane_bound.json" 2> "$OUT/${TAG}_bench_c3_lane_bound.err" || exit 1
 echo "variants done"
+timeout -k 10 500 python3 bench.py --workload c5 --steps 1 --warmup 1 > "$OUT/${TAG}_bench_c5_full.json" 2> "$OUT/${TAG}_bench_c5.err" || exit 1
+echo "c5 done"
