@@ -484,15 +484,15 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
 }
 
 // The regrouping variant of the persistent kernel (flat worlds): same launch shape.
-template <int MODE, bool TABLES>
+template <int MODE, bool TABLES, bool TIMELESS, bool BOXED = false>
 int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &film, unsigned long long total) {
-    auto kernel = k_paths_regroup<MODE, TABLES>;
+    auto kernel = k_paths_regroup<MODE, TABLES, TIMELESS, BOXED>;
     int per_cu = 0, n_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     if (per_cu < 1 || n_cu < 1) return fail(h, "rt_render: path kernel does not fit on a compute unit");
     if (p->waves_per_simd && int(p->waves_per_simd) < per_cu) per_cu = int(p->waves_per_simd);
-    const unsigned long long per_block = (unsigned long long)REGROUP_SLOTS * (BLOCK / WAVE);
+    const unsigned long long per_block = (unsigned long long)RegroupPool<TIMELESS>::SLOTS * (BLOCK / WAVE);
     unsigned long long blocks_needed = (total + per_block - 1) / per_block;
     unsigned long long blocks = (unsigned long long)per_cu * n_cu;
     if (blocks > blocks_needed) blocks = blocks_needed;
@@ -566,10 +566,16 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     if (h->accel == ACCEL_FLAT && regroup_wanted && regroup_fits) {
         // a small scene's quads, spheres and materials are copied into LDS tables
         const bool tables = h->n_quads <= TABLE_QUADS && h->n_spheres <= TABLE_SPHERES && h->n_materials <= TABLE_MATERIALS;
-        if (p->mode == RT_MODE_REF_EXACT)
-            rc = tables ? launch_paths_regroup<RT_MODE_REF_EXACT, true>(h, p, film, total) : launch_paths_regroup<RT_MODE_REF_EXACT, false>(h, p, film, total);
-        else
-            rc = tables ? launch_paths_regroup<RT_MODE_BOOK3, true>(h, p, film, total) : launch_paths_regroup<RT_MODE_BOOK3, false>(h, p, film, total);
+        // (in a scene in which nothing moves a slot of the pool does without the ray's time: more slots)
+        // (a Cornell box -- rectangles, upright boxes, spheres, no medium -- takes a scan without the other loops)
+        const bool boxed = tables && !h->has_media && h->sc.n_flat_pairs == 0 && h->sc.n_flat_quads == 0 && h->sc.n_flat_other == 0 &&
+                           h->sc.n_flat_boxes == h->sc.n_flat_boxes_aligned + h->sc.n_flat_boxes_upright;
+#define RT_REGROUP(MODE)                                                                                                  \
+    (boxed  ? (dc.timeless ? launch_paths_regroup<MODE, true, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false, true>(h, p, film, total)) \
+     : tables ? (dc.timeless ? launch_paths_regroup<MODE, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false>(h, p, film, total)) \
+            : (dc.timeless ? launch_paths_regroup<MODE, false, true>(h, p, film, total) : launch_paths_regroup<MODE, false, false>(h, p, film, total)))
+        rc = p->mode == RT_MODE_REF_EXACT ? RT_REGROUP(RT_MODE_REF_EXACT) : RT_REGROUP(RT_MODE_BOOK3);
+#undef RT_REGROUP
     } else if (accel_is_wide(h->accel) && regroup_fits &&
                ((p->flags & RT_FLAG_REGROUP) || (regroup_wanted && h->accel_stats.nodes >= POOL_MIN_NODES))) {
         // behind a tree the pool of paths per wave pays where traversals are long (measured: +14 % at 466 k

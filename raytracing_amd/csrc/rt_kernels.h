@@ -817,6 +817,11 @@ __device__ __forceinline__ QuadRec load_quad_rec(const RT_CONST_AS float *p) {
     for (int i = 0; i < 16; ++i) r.f[i] = p[i];
     return r;
 }
+// BOXED: the caller knows that the list's quads are all rectangle or box records and that whatever else
+// it holds is a packed sphere (a Cornell box): the loops over pairs, general quads, boxes in a general
+// frame and primitives by reference are compiled out -- with them in, their registers and their
+// hoisted set-up are paid for by a scan that never runs them.
+template <bool BOXED = false>
 __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, float tlo, float thi,
                                           uint32_t origin_ref, const RayCtx &rc, Best &best) {
     best.t = thi;
@@ -850,7 +855,7 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
     // packed array ends with an all-zero record after an odd count (a zero normal never hits)
     // and one more after that, so requests need no bounds and the loop body has no branch.
     // The asm statements keep each request where it is written.
-    if (sc.n_flat_pairs) {
+    if (!BOXED && sc.n_flat_pairs) {
         // Parallelograms only (the usual case: walls and boxes): two quads per record, their
         // fields interleaved so that every packed instruction takes its scalar operand straight
         // from the loaded register pair, and the accept rule folded into two max3 and a compare
@@ -889,7 +894,7 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
                 best.ref = ok ? r : best.ref;
             }
         }
-    } else if (nq) {
+    } else if (!BOXED && nq) {
         QuadRec a = load_quad_rec(Q);
         for (uint32_t k = 0; k < nq; k += 2) {
             const QuadRec b = load_quad_rec(Q + 16 * size_t(k + 1));
@@ -991,7 +996,7 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
             const float od2 = fmaf(B[6], ocx, B[8] * ocz), dd2 = fmaf(B[6], d.x, B[8] * d.z);
             closest(axis(0, od0, dd0, __builtin_amdgcn_rcpf(dd0)), axis(1, o.y, d.y, inv_dy), axis(2, od2, dd2, __builtin_amdgcn_rcpf(dd2)));
         }
-        for (; k < n_boxes; ++k, B += 32) {
+        for (; !BOXED && k < n_boxes; ++k, B += 32) {
             const V3 oc = {o.x - B[9], o.y - B[10], o.z - B[11]};
             float od[3], dd[3];
 #pragma unroll
@@ -1014,7 +1019,7 @@ __device__ __forceinline__ void scan_flat(SceneRef sc, V3 o, V3 d, float time, f
         best.ref = h ? r : best.ref;
     }
     const RT_CONST_AS uint32_t *other = as_uniform(sc.flat_other);
-    for (uint32_t k = 0; k < sc.n_flat_other; ++k) test_prim<true>(sc, other[k], o, d, time, tlo, origin_ref, rc, best);
+    for (uint32_t k = 0; !BOXED && k < sc.n_flat_other; ++k) test_prim<true>(sc, other[k], o, d, time, tlo, origin_ref, rc, best);
 }
 
 template <int ACCEL, bool USE_LDS_NODES>
@@ -1832,25 +1837,30 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
 // Exit: a wave leaves when the sample counter has run out and every list but the free one is
 // empty; each step moves its slots on and a path ends within max_depth bounces.
 #ifndef RT_REGROUP_SLOTS
-#define RT_REGROUP_SLOTS 168
+#define RT_REGROUP_SLOTS 172
 #endif
-constexpr int REGROUP_SLOTS = RT_REGROUP_SLOTS;
+#ifndef RT_REGROUP_SLOTS_TIMELESS
+#define RT_REGROUP_SLOTS_TIMELESS 184
+#endif
+// slots of a wave's pool: in a scene in which nothing moves a slot does without the ray's time
+constexpr int REGROUP_SLOTS = RT_REGROUP_SLOTS, REGROUP_SLOTS_TIMELESS = RT_REGROUP_SLOTS_TIMELESS;
 enum : uint32_t { RG_FREE = 0, RG_RAY = 1, RG_DIFFUSE = 2, RG_METAL = 3, RG_GLASS = 4, RG_END = 5, RG_LISTS = 6 };
-constexpr uint32_t RG_REF_NOTHING = 0xFFFFFFFEu; // in place of a hit's ref: the path ended with nothing to deposit
-// A slot is 52 bytes + 6 list bytes: the pool size sets how full the turns run (measured on the
-// Book-3 Cornell box: 96 slots 34.8, 128 42.0, 144 43.8, 176 45.9 G segments/s), and the 16 waves
-// of a compute unit share 160 KB: 4 x 168 slots is 38 976 bytes a block, the scene tables
-// (FlatTables) take 1 664 more.
+constexpr uint32_t RG_REF_NOTHING = 0xFFFFFFFEu; // in place of a hit's ref: the path ended with nothing to deposit, or the slot never held one
+// A slot is 52 bytes + 5 list bytes (48 + 5 when nothing moves): the pool size sets how full the turns
+// run (measured on the Book-3 Cornell box: 96 slots 34.8, 128 42.0, 144 43.8, 176 45.9 G segments/s),
+// and the 16 waves of a compute unit share 160 KB: 4 x 172 (184) slots are 39 232 (39 040) bytes a
+// block, the scene tables (FlatTables) take 1 728 more.
 //   ra: origin and time; once the closest hit is found, the hit point and time
 //   rb: direction and the ref of the primitive the ray leaves; once the hit is found, the hit's ref
-//   sa: throughput and pixel;  sb: stratum | bounce << 24
-struct RegroupPool {
-    float4 ra[REGROUP_SLOTS], rb[REGROUP_SLOTS], sa[REGROUP_SLOTS];
-    uint32_t sb[REGROUP_SLOTS];
-    uint8_t list[RG_LISTS][REGROUP_SLOTS];
+//   sa: throughput and pixel;  sb: stratum | bounce << 24 (TIMELESS: in ra.w, where the time would be)
+template <bool TIMELESS> struct alignas(16) RegroupPool {
+    static constexpr int SLOTS = TIMELESS ? REGROUP_SLOTS_TIMELESS : REGROUP_SLOTS;
+    float4 ra[SLOTS], rb[SLOTS], sa[SLOTS];
+    uint32_t sb[TIMELESS ? 1 : SLOTS];
+    uint8_t list[RG_LISTS - 1][SLOTS]; // list `which` at [which - 1]: a free slot waits in the end list (k_paths_regroup)
 };
 constexpr uint32_t REGROUP_MAX_STRATA = 1u << 24, REGROUP_MAX_DEPTH = 255u; // what sb holds
-static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE, "slot numbers are bytes");
+static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE && REGROUP_SLOTS_TIMELESS <= 256 && REGROUP_SLOTS_TIMELESS >= WAVE, "slot numbers are bytes");
 #ifndef RT_REGROUP_WAVES
 #define RT_REGROUP_WAVES 4
 #endif
@@ -1862,13 +1872,17 @@ static_assert(RG_STATS == RG_LISTS + 2, "the lists' steps, then harvest and refi
 #endif
 
 // TABLES: the scene is small enough for FlatTables (the launch checks the counts).
-template <int MODE, bool TABLES>
+// TIMELESS: nothing in the scene moves, every ray's time is 0 (DCamera::timeless) and a slot does without it.
+// BOXED: see scan_flat (such a world has no medium).
+template <int MODE, bool TABLES, bool TIMELESS, bool BOXED = false>
 __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const DScene *scp, const DCamera *camp, Film film, uint32_t k0,
                                                           uint32_t k1, Ctrl *ctrl, uint32_t has_media, uint32_t grab,
                                                           uint32_t n_quads, uint32_t n_spheres, uint32_t n_mats, uint32_t first_take) {
     SceneRef sc = *as_uniform(scp);
     CamRef cam = *as_uniform(camp);
-    __shared__ RegroupPool s_pool[BLOCK / WAVE];
+    typedef RegroupPool<TIMELESS> Pool;
+    constexpr uint32_t SLOTS = Pool::SLOTS;
+    __shared__ Pool s_pool[BLOCK / WAVE];
     __shared__ float4 s_quad_nm[TABLES ? TABLE_QUADS : 1], s_spheres[TABLES ? 3 * TABLE_SPHERES : 1];
     __shared__ rt_material s_mats[TABLES ? TABLE_MATERIALS : 1];
     __shared__ uint8_t s_next[TABLES ? TABLE_QUADS + TABLE_SPHERES + 8 : 1];
@@ -1891,11 +1905,23 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         __syncthreads();
     }
     const FlatTables tb{s_quad_nm, s_spheres, s_mats};
-    RegroupPool &pool = s_pool[threadIdx.x / WAVE];
+    Pool &pool = s_pool[threadIdx.x / WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    for (uint32_t i = lane; i < uint32_t(REGROUP_SLOTS); i += WAVE) pool.list[RG_FREE][i] = uint8_t(i);
+    // A slot that holds no path waits in the end list with nothing to deposit: the end step gives it
+    // the next sample, as it does to a slot whose path has just ended.  (A list of free slots beside it
+    // was one more byte per slot and one more count to compare.)
+    for (uint32_t i = lane; i < SLOTS; i += WAVE) {
+        pool.list[RG_END - 1][i] = uint8_t(i);
+        pool.rb[i].w = bitsf(RG_REF_NOTHING);
+    }
     // list lengths, wave-uniform
-    uint32_t n_free = REGROUP_SLOTS, n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0, n_end = 0;
+    uint32_t n_ray = 0, n_diffuse = 0, n_metal = 0, n_glass = 0, n_end = SLOTS;
+    // stratum | bounce << 24 of a slot: a word of its own, or (TIMELESS) the w of ra in place of the time
+    auto get_sb = [&](uint32_t slot, const float4 &ra) { return TIMELESS ? fbits(ra.w) : pool.sb[slot]; };
+    auto timed = [&](float4 ra) { // the slot's ra as the shading code reads it: w is the ray's time
+        if (TIMELESS) ra.w = 0.0f;
+        return ra;
+    };
     // The wave owns a range of sample ids: `remaining` of them are left, the next one is (next_pixel,
     // next_stratum).  `left` is how many the whole frame had left when the wave last asked the counter.
     // (Counts instead of 64-bit ids: the kernel sits at the limit of scalar registers.)
@@ -1927,7 +1953,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         const unsigned long long mask = __ballot(yes);
         if (mask == 0) return; // uniform
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-        if (yes) pool.list[which][n + prefix] = uint8_t(slot);
+        if (yes) pool.list[which - 1][n + prefix] = uint8_t(slot);
         n += uint32_t(__popcll(mask));
     };
     // up to `want` new samples from the wave's range (asking the counter for a new range when it
@@ -1959,11 +1985,11 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
             V3 o, d;
             float time;
             camera_ray(cam, px, st, rng, o, d, time);
-            pool.ra[slot] = make_float4(o.x, o.y, o.z, time);
+            pool.ra[slot] = make_float4(o.x, o.y, o.z, TIMELESS ? bitsf(st) : time);
             pool.rb[slot] = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
             pool.sa[slot] = make_float4(1.f, 1.f, 1.f, bitsf(px));
-            pool.sb[slot] = st;
-            pool.list[RG_RAY][n_ray + lane] = uint8_t(slot);
+            if (!TIMELESS) pool.sb[slot] = st;
+            pool.list[RG_RAY - 1][n_ray + lane] = uint8_t(slot);
         }
         n_ray += m;
         remaining -= m;
@@ -1977,7 +2003,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         // without a barrier; the fence keeps the compiler from moving accesses across turns
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // the fullest list, 64 counting as full; among equally full lists the first of ray, diffuse, glass,
-        // metal, end, free.  Most turns find a full list: those are spared the comparison of all six counts
+        // metal, end.  Most turns find a full list: those are spared the comparison of all six counts
         // (sixty-five scalar instructions a turn, two fifths of the kernel's scalar work).
         uint32_t stage = RG_RAY, most = uint32_t(WAVE);
 #ifndef RT_NO_FAST_LIST_CHOICE
@@ -1998,7 +2024,6 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
             offer(RG_GLASS, n_glass);
             offer(RG_METAL, n_metal);
             offer(RG_END, n_end);
-            if (!exhausted) offer(RG_FREE, n_free);
             if (most == 0) break;
         }
 #ifdef RT_REGROUP_STATS
@@ -2006,13 +2031,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
         const uint32_t rg_stage = stage;
 #endif
 
-        if (stage == RG_FREE) {
-            // slots that hold no path yet (the start of the frame)
-            const uint32_t slot = lane < most ? pool.list[RG_FREE][n_free - 1 - lane] : 0u;
-            const uint32_t m = new_paths(most, slot);
-            RT_RG_COUNT(RG_FREE, m);
-            n_free -= m; // the first m lanes took the last m entries
-        } else if (stage == RG_END) {
+        if (stage == RG_END) {
             // what the path's last hit contributes -- background or emission (camera.rs:445-453)
             // -- and the next sample into the same slot
             const uint32_t m = most;
@@ -2021,15 +2040,20 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
             const bool active = lane < m;
             uint32_t slot = 0;
             if (active) {
-                slot = pool.list[RG_END][n_end + lane];
+                slot = pool.list[RG_END - 1][n_end + lane];
                 const float4 rb = pool.rb[slot];
                 if (fbits(rb.w) != RG_REF_NOTHING) {
                     Surface sf; // ra holds the hit point: t = 0 from there
-                    (void)shade_emit<true, TABLES>(sc, cam, film, pool.ra[slot], rb, pool.sa[slot], make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
+                    (void)shade_emit<true, TABLES>(sc, cam, film, timed(pool.ra[slot]), rb, pool.sa[slot], make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
                 }
             }
             const uint32_t taken = new_paths(m, slot);
-            push(RG_FREE, n_free, active && lane >= taken, slot); // no samples left: the slot stays empty
+            // A slot that got no sample waits on with nothing to deposit until the wave's next range has
+            // come; once the frame's samples have run out it leaves the lists for good.
+            if (taken < m && !exhausted) {
+                if (active && lane >= taken) pool.rb[slot].w = bitsf(RG_REF_NOTHING);
+                push(RG_END, n_end, active && lane >= taken, slot);
+            }
         } else if (stage == RG_RAY) {
             // closest hit (camera.rs:444)
             const uint32_t m = most;
@@ -2039,19 +2063,19 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
             const bool active = lane < m;
             uint32_t slot = 0, kind = RG_LISTS;
             if (active) {
-                slot = pool.list[RG_RAY][n_ray + lane];
+                slot = pool.list[RG_RAY - 1][n_ray + lane];
                 const float4 ra = pool.ra[slot], rb = pool.rb[slot];
                 RayCtx rc{k0, k1, 0u, 0u, 0u};
-                if (has_media) { // a medium keys its free-flight draw by the sample and the bounce
-                    const uint32_t sb = pool.sb[slot];
+                if (!BOXED && has_media) { // a medium keys its free-flight draw by the sample and the bounce
+                    const uint32_t sb = get_sb(slot, ra);
                     rc.pixel = fbits(pool.sa[slot].w), rc.sample = sb & 0xFFFFFFu, rc.bounce = sb >> 24;
                 }
                 Best best;
-                scan_flat(sc, mk(ra), mk(rb), ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
+                scan_flat<BOXED>(sc, mk(ra), mk(rb), TIMELESS ? 0.0f : ra.w, 0.001f, RT_INF, fbits(rb.w), rc, best);
                 // the material's kind decides where the path waits next; a miss ends it like a light
                 uint32_t type = RT_MAT_LIGHT;
                 bool looked_up = false;
-                if (TABLES && !has_media) { // one table read by (kind, index); a miss reads the table's last entry
+                if (TABLES && (BOXED || !has_media)) { // one table read by (kind, index); a miss reads the table's last entry
                     const uint32_t pk = best.ref >> RT_REF_KIND_SHIFT, idx = best.ref & RT_REF_INDEX_MASK;
                     const uint32_t at = best.ref == RT_REF_NONE ? TABLE_QUADS + TABLE_SPHERES : (pk == RT_KIND_SPHERE ? TABLE_QUADS + idx : idx);
                     kind = s_next[at];
@@ -2089,9 +2113,10 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 uint32_t slot = 0;
                 bool alive = false, again = false; // again: the next hit is known and is a vertex of this kind
                 if (active) {
-                    slot = pool.list[stage][n_list + lane];
+                    slot = pool.list[stage - 1][n_list + lane];
                     float4 ra = pool.ra[slot], rb = pool.rb[slot], sa = pool.sa[slot];
-                    const uint32_t packed = pool.sb[slot];
+                    const uint32_t packed = get_sb(slot, ra);
+                    ra = timed(ra);
                     uint2 sb = make_uint2(packed & 0xFFFFFFu, packed >> 24);
                     Surface sf; // ra holds the hit point: t = 0 from there
                     (void)shade_emit<false, TABLES>(sc, cam, film, ra, rb, sa, make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
@@ -2116,10 +2141,11 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                         }
                     }
                     if (alive) {
+                        if (TIMELESS) ra.w = bitsf(sb.x | (sb.y << 24));
+                        else pool.sb[slot] = sb.x | (sb.y << 24);
                         pool.ra[slot] = ra;
                         pool.rb[slot] = rb;
                         pool.sa[slot] = sa;
-                        pool.sb[slot] = sb.x | (sb.y << 24);
                     } else {
                         pool.rb[slot].w = bitsf(RG_REF_NOTHING);
                     }
