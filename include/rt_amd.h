@@ -190,6 +190,19 @@ typedef struct {
  * Regrouping needs max_depth <= 255 and falls back otherwise. */
 #define RT_FLAG_REGROUP 4u
 #define RT_FLAG_NO_REGROUP 8u
+/* The persistent kernels are compiled several times: for any scene, and without the code for what a
+ * scene may lack (motion, media and textures behind a tree; in a flat world also every loop of the
+ * scan but those over rectangle, upright-box and sphere records).  rt_render takes the variant that
+ * fits the uploaded scene -- the same samples and the same arithmetic, fewer registers.
+ * RT_FLAG_GENERAL_KERNELS takes the kernels compiled for any scene (tests compare the two). */
+#define RT_FLAG_GENERAL_KERNELS 16u
+/* Which compilation of the persistent kernel the last rt_render on this handle took (0 before any, and
+ * after a wavefront render).  A diagnostic without a counterpart in the reference. */
+#define RT_VARIANT_REGROUPED 1u /* paths regrouped per wave (rt_stats.regrouped) */
+#define RT_VARIANT_TIMELESS 2u  /* flat world, nothing moves: pool slots without the ray's time */
+#define RT_VARIANT_BOXED 4u     /* flat world of rectangle, upright-box and sphere records only */
+#define RT_VARIANT_PLAIN 8u     /* behind a tree: no motion, no medium, no texture but colours */
+#define RT_VARIANT_EXTRAS 16u   /* behind a tree: box leaves or primitives tested after the walk */
 typedef struct {
     uint32_t struct_size;                /* = sizeof(rt_render_params) of the caller's header */
     uint32_t mode;
@@ -302,6 +315,9 @@ int rt_accel_selftest(const rt_scene_desc *scene, uint32_t builder, rt_accel_inf
  * radiance is ADDED into the film (planar fp32 sums in HBM).  Asynchronous on the stream
  * except for the completion polling it does itself; returns when all paths have finished. */
 int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *params);
+/* RT_VARIANT_* bits of the persistent kernel the last rt_render on this handle took (a diagnostic, no
+ * counterpart in the reference; h may be NULL: 0). */
+uint32_t rt_last_kernel_variant(const rt_handle *h);
 
 /* Film = 3 planes of width*height fp32 SUMS (R plane, G plane, B plane). */
 int rt_film_clear(rt_handle *h);

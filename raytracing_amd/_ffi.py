@@ -110,6 +110,8 @@ RT_FLAG_TIME_KERNELS = 1
 RT_FLAG_WAVEFRONT = 2
 RT_FLAG_REGROUP = 4
 RT_FLAG_NO_REGROUP = 8
+RT_FLAG_GENERAL_KERNELS = 16
+RT_VARIANT_REGROUPED, RT_VARIANT_TIMELESS, RT_VARIANT_BOXED, RT_VARIANT_PLAIN, RT_VARIANT_EXTRAS = 1, 2, 4, 8, 16
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
 RT_COMM_ID_BYTES = 128
 RT_NODE_LEAF = 0xFFFFFFFF
@@ -119,6 +121,7 @@ _vp = C.c_void_p
 _d3 = P(f64)
 SIGNATURES = {
     "rt_abi_version": (u32, []),
+    "rt_last_kernel_variant": (u32, [_vp]),
     "rt_device_count": (C.c_int, [P(C.c_int)]),
     "rt_create": (C.c_int, [C.c_int, P(_vp)]),
     "rt_destroy": (None, [_vp]),

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _ffi
-from ._ffi import (CameraBuilderStruct, RtCamera, RtRenderParams, RtSceneDesc, RtStats, RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT, RT_FLAG_REGROUP, RT_FLAG_NO_REGROUP,
+from ._ffi import (CameraBuilderStruct, RtCamera, RtRenderParams, RtSceneDesc, RtStats, RT_FLAG_TIME_KERNELS, RT_FLAG_WAVEFRONT, RT_FLAG_REGROUP, RT_FLAG_NO_REGROUP, RT_FLAG_GENERAL_KERNELS,
                    RT_MODE_BOOK3, RT_MODE_REF_EXACT)
 
 SHAPE_PARALLELOGRAM, SHAPE_TRIANGLE, SHAPE_DISC = 0, 1, 2
@@ -315,16 +315,22 @@ class Device:
     def film_clear(self):
         self._check(self.lib.rt_film_clear(self.h), "rt_film_clear")
 
+    def last_kernel_variant(self):
+        """RT_VARIANT_* bits of the persistent kernel the last render took (0 after a wavefront render)."""
+        return int(self.lib.rt_last_kernel_variant(self.h))
+
     def render(self, cam: RtCamera, mode=RT_MODE_REF_EXACT, seed=1, stratum_begin=0, stratum_end=0, pool_size=0,
-               time_kernels=False, time_every=0, wavefront=False, refill_min=0, waves_per_simd=0, regroup=None):
+               time_kernels=False, time_every=0, wavefront=False, refill_min=0, waves_per_simd=0, regroup=None, general_kernels=False):
         """Adds strata [begin, end) of every pixel into the film (camera.rs:386-401).
         wavefront=True takes the ray-queue pipeline instead of the persistent path kernel.
         regroup: True / False forces the persistent kernel's regrouping or lane-bound variant on a
-        flat world, None leaves the choice to the library."""
+        flat world, None leaves the choice to the library.  general_kernels=True takes the kernels
+        compiled for any scene instead of the variants compiled for what this scene lacks."""
         p = RtRenderParams()
         p.mode, p.seed = mode, seed
         p.flags = (RT_FLAG_TIME_KERNELS if time_kernels else 0) | (RT_FLAG_WAVEFRONT if wavefront else 0) | \
-            (0 if regroup is None else (RT_FLAG_REGROUP if regroup else RT_FLAG_NO_REGROUP))
+            (0 if regroup is None else (RT_FLAG_REGROUP if regroup else RT_FLAG_NO_REGROUP)) | \
+            (RT_FLAG_GENERAL_KERNELS if general_kernels else 0)
         p.refill_min, p.waves_per_simd = refill_min, waves_per_simd
         p.stratum_begin, p.stratum_end, p.pool_size, p.time_every = stratum_begin, stratum_end, pool_size, time_every
         self._check(self.lib.rt_render(self.h, C.byref(cam), C.byref(p)), "rt_render")

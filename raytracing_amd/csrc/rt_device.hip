@@ -59,6 +59,8 @@ struct rt_handle {
     uint32_t has_media = 0, n_prims = 0, alone_spheres = 0, n_quads = 0, n_spheres = 0, n_materials = 0;
     bool has_specular = false;
     bool has_motion = false; // some sphere moves: a ray's time matters
+    uint32_t last_variant = 0;    // RT_VARIANT_* of the persistent kernel the last rt_render took
+    bool plain_materials = false; // no Isotropic material, every texture a colour folded into its material's record
     uint32_t n_textures = 0;
     std::vector<uint32_t> prim_to_ref; // user-visible primitive id -> ref (parity hook)
 
@@ -454,10 +456,10 @@ void drain_timers(rt_handle *h, size_t upto) {
 void drain_timers(rt_handle *h) { drain_timers(h, h->ev_used); }
 
 // One launch of the persistent path kernel: as many blocks as the device keeps resident.
-template <int MODE, int ACCEL, bool EXTRAS = true>
+template <int MODE, int ACCEL, bool EXTRAS = true, bool PLAIN = false>
 int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
                  unsigned long long total) {
-    auto kernel = k_paths<MODE, ACCEL, EXTRAS>;
+    auto kernel = k_paths<MODE, ACCEL, EXTRAS, PLAIN>;
     int per_cu = 0, n_cu = 0;
     const size_t dyn_lds = accel_is_wide(ACCEL) ? h->dyn_lds4() : 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));
@@ -517,9 +519,9 @@ int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &fi
 
 // The regrouping kernel behind the wide BVH: a pool of paths per wave, traversals resumable per lane.
 constexpr uint32_t POOL_MIN_NODES = 8192; // trees from this size take it by default
-template <int MODE, bool QUANT, bool EXTRAS>
+template <int MODE, bool QUANT, bool EXTRAS, bool PLAIN = false>
 int launch_paths_pool(rt_handle *h, const rt_render_params *p, const Film &film, unsigned long long total) {
-    auto kernel = k_paths_pool<MODE, QUANT, EXTRAS>;
+    auto kernel = k_paths_pool<MODE, QUANT, EXTRAS, PLAIN>;
     // what is left of a quarter of the CU's LDS behind pools and stacks holds the top of the tree
     const size_t node_bytes = QUANT ? sizeof(Node4Q) : sizeof(Node4), budget = 40 * 1024;
     const uint32_t lds_nodes = POOL_LDS_FIXED < budget ? uint32_t(std::min<size_t>(h->accel_stats.nodes, (budget - POOL_LDS_FIXED) / node_bytes)) : 0u;
@@ -563,38 +565,54 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     // box leaves in the wide tree, or primitives kept out of it and tested after the walk: the kernels
     // behind a tree are compiled with and without the code for them
     const bool extras = h->n_box_leaves != 0 || h->sc.n_post != 0;
+    // ... and, for scenes with neither, once more without the code for motion, media and textures
+    const bool general = (p->flags & RT_FLAG_GENERAL_KERNELS) != 0;
+    uint32_t variant_flat = 0;
+    const bool plain = !general && !extras && dc.timeless && !h->has_media && h->plain_materials;
     if (h->accel == ACCEL_FLAT && regroup_wanted && regroup_fits) {
         // a small scene's quads, spheres and materials are copied into LDS tables
         const bool tables = h->n_quads <= TABLE_QUADS && h->n_spheres <= TABLE_SPHERES && h->n_materials <= TABLE_MATERIALS;
         // (in a scene in which nothing moves a slot of the pool does without the ray's time: more slots)
         // (a Cornell box -- rectangles, upright boxes, spheres, no medium -- takes a scan without the other loops)
-        const bool boxed = tables && !h->has_media && h->sc.n_flat_pairs == 0 && h->sc.n_flat_quads == 0 && h->sc.n_flat_other == 0 &&
+        const bool timeless = dc.timeless && !general;
+        const bool boxed = !general && tables && !h->has_media && h->sc.n_flat_pairs == 0 && h->sc.n_flat_quads == 0 && h->sc.n_flat_other == 0 &&
                            h->sc.n_flat_boxes == h->sc.n_flat_boxes_aligned + h->sc.n_flat_boxes_upright;
 #define RT_REGROUP(MODE)                                                                                                  \
-    (boxed  ? (dc.timeless ? launch_paths_regroup<MODE, true, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false, true>(h, p, film, total)) \
-     : tables ? (dc.timeless ? launch_paths_regroup<MODE, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false>(h, p, film, total)) \
-            : (dc.timeless ? launch_paths_regroup<MODE, false, true>(h, p, film, total) : launch_paths_regroup<MODE, false, false>(h, p, film, total)))
+    (boxed  ? (timeless ? launch_paths_regroup<MODE, true, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false, true>(h, p, film, total)) \
+     : tables ? (timeless ? launch_paths_regroup<MODE, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false>(h, p, film, total)) \
+            : (timeless ? launch_paths_regroup<MODE, false, true>(h, p, film, total) : launch_paths_regroup<MODE, false, false>(h, p, film, total)))
         rc = p->mode == RT_MODE_REF_EXACT ? RT_REGROUP(RT_MODE_REF_EXACT) : RT_REGROUP(RT_MODE_BOOK3);
 #undef RT_REGROUP
+        variant_flat = (timeless ? RT_VARIANT_TIMELESS : 0u) | (boxed ? RT_VARIANT_BOXED : 0u);
     } else if (accel_is_wide(h->accel) && regroup_fits &&
                ((p->flags & RT_FLAG_REGROUP) || (regroup_wanted && h->accel_stats.nodes >= POOL_MIN_NODES))) {
         // behind a tree the pool of paths per wave pays where traversals are long (measured: +14 % at 466 k
         // nodes, -2 % at 232); RT_FLAG_REGROUP asks for it on any tree
 #define RT_POOL(MODE)                                                                                                        \
-    (h->accel == ACCEL_BVH4Q ? (extras ? launch_paths_pool<MODE, true, true>(h, p, film, total) : launch_paths_pool<MODE, true, false>(h, p, film, total)) \
-                             : (extras ? launch_paths_pool<MODE, false, true>(h, p, film, total) : launch_paths_pool<MODE, false, false>(h, p, film, total)))
+    (h->accel == ACCEL_BVH4Q ? (extras  ? launch_paths_pool<MODE, true, true>(h, p, film, total)                               \
+                                : plain ? launch_paths_pool<MODE, true, false, true>(h, p, film, total)                        \
+                                        : launch_paths_pool<MODE, true, false>(h, p, film, total))                             \
+                             : (extras  ? launch_paths_pool<MODE, false, true>(h, p, film, total)                              \
+                                : plain ? launch_paths_pool<MODE, false, false, true>(h, p, film, total)                       \
+                                        : launch_paths_pool<MODE, false, false>(h, p, film, total)))
         rc = p->mode == RT_MODE_REF_EXACT ? RT_POOL(RT_MODE_REF_EXACT) : RT_POOL(RT_MODE_BOOK3);
 #undef RT_POOL
     } else {
 #define RT_PATHS(MODE)                                                                                    \
     (h->accel == ACCEL_FLAT   ? launch_paths<MODE, ACCEL_FLAT>(h, dc, p, film, total)                        \
-     : h->accel == ACCEL_BVH4 ? (extras ? launch_paths<MODE, ACCEL_BVH4, true>(h, dc, p, film, total) : launch_paths<MODE, ACCEL_BVH4, false>(h, dc, p, film, total))    \
-     : h->accel == ACCEL_BVH4Q ? (extras ? launch_paths<MODE, ACCEL_BVH4Q, true>(h, dc, p, film, total) : launch_paths<MODE, ACCEL_BVH4Q, false>(h, dc, p, film, total)) \
+     : h->accel == ACCEL_BVH4 ? (extras  ? launch_paths<MODE, ACCEL_BVH4, true>(h, dc, p, film, total)                \
+                                 : plain ? launch_paths<MODE, ACCEL_BVH4, false, true>(h, dc, p, film, total)         \
+                                         : launch_paths<MODE, ACCEL_BVH4, false>(h, dc, p, film, total))              \
+     : h->accel == ACCEL_BVH4Q ? (extras  ? launch_paths<MODE, ACCEL_BVH4Q, true>(h, dc, p, film, total)              \
+                                  : plain ? launch_paths<MODE, ACCEL_BVH4Q, false, true>(h, dc, p, film, total)       \
+                                          : launch_paths<MODE, ACCEL_BVH4Q, false>(h, dc, p, film, total))            \
                               : launch_paths<MODE, ACCEL_BVH2>(h, dc, p, film, total))
     rc = p->mode == RT_MODE_REF_EXACT ? RT_PATHS(RT_MODE_REF_EXACT) : RT_PATHS(RT_MODE_BOOK3);
 #undef RT_PATHS
     }
     if (rc) return rc;
+    h->last_variant = (h->stats.regrouped ? RT_VARIANT_REGROUPED : 0u) | (h->accel != ACCEL_FLAT && extras ? RT_VARIANT_EXTRAS : 0u) |
+                      (h->accel != ACCEL_FLAT && plain ? RT_VARIANT_PLAIN : 0u) | variant_flat;
     RT_HIP(hipEventRecord(h->ev_end, h->stream));
     RT_HIP(hipMemcpyAsync(&h->h_ctrl[0], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     RT_HIP(hipStreamSynchronize(h->stream));
@@ -678,6 +696,7 @@ int rt_debug_regroup_stats(unsigned long long *out) {
 #endif
 
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+uint32_t rt_last_kernel_variant(const rt_handle *h) { return h ? h->last_variant : 0u; }
 
 int rt_device_count(int *n) {
     rt_handle *h = nullptr;
@@ -808,6 +827,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     // device copy of the materials: a SolidColor texture is folded into the material record
     // (albedo + pad = 1) so that shading such a surface does not chase the texture record
     std::vector<rt_material> mats(s->materials, s->materials + s->n_materials);
+    bool plain_materials = true;
     for (rt_material &m : mats) {
         m.pad = 0;
         const bool textured = m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LIGHT || m.type == RT_MAT_ISOTROPIC;
@@ -815,6 +835,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
             std::memcpy(m.albedo, s->textures[m.tex].color, sizeof(m.albedo));
             m.pad = 1;
         }
+        if ((textured && !m.pad) || m.type == RT_MAT_ISOTROPIC) plain_materials = false;
     }
     // A world that is one list of primitives takes the stack-free scan (rt_flat.h): its quads packed
     // in list order for scalar loads, boxes and a room as slab tests, everything else by reference.
@@ -955,6 +976,7 @@ int rt_upload_scene(rt_handle *h, const rt_scene_desc *s) {
     h->sc = d;
     h->have_scene = true;
     h->has_media = s->n_media ? 1u : 0u;
+    h->plain_materials = plain_materials;
     h->n_box_leaves = uint32_t(wide_boxes.size());
     h->n_quads = s->n_quads, h->n_spheres = s->n_spheres, h->n_materials = s->n_materials;
     h->alone_spheres = 0;

@@ -232,10 +232,12 @@ struct SphereEq { // a t^2 - 2 h t + c = 0 for one ray and one sphere, plain fp3
     V3 center, oc;
     float r, pr, a, inv_a, h, b2, disc;
 };
+// STATIC: the sphere does not move (s1 is not looked at)
+template <bool STATIC = false>
 __device__ __forceinline__ SphereEq sphere_eq(float4 s0, float4 s1, V3 o, V3 d, float time) {
 #pragma clang fp contract(off) // the error terms in sphere_roots must see the same roundings as these sums
     SphereEq q;
-    q.center = fma3(mk(s1), time, mk(s0));
+    q.center = STATIC ? mk(s0) : fma3(mk(s1), time, mk(s0));
     q.r = s0.w, q.pr = q.r * q.r;
     q.a = len2(d);
     q.inv_a = rcp(q.a); // v_rcp_f32, 1 ulp (the compiler's 1/x costs ten instructions here)
@@ -277,9 +279,10 @@ __device__ __forceinline__ bool sphere_roots(const SphereEq &q, V3 o, V3 d, floa
     t_near = fminf(ta, tb), t_far = fmaxf(ta, tb);
     return true;
 }
+template <bool STATIC = false>
 __device__ __forceinline__ bool hit_sphere(float4 s0, float4 s1, V3 o, V3 d, float time, float tlo, float thi,
                                            bool from_self, float &t) {
-    const SphereEq q = sphere_eq(s0, s1, o, d, time);
+    const SphereEq q = sphere_eq<STATIC>(s0, s1, o, d, time);
     if (from_self) {
         const float root = 2.0f * q.h * q.inv_a;
         if (!(tlo < root && root < thi)) return false;
@@ -297,9 +300,11 @@ __device__ __forceinline__ bool hit_sphere(float4 s0, float4 s1, V3 o, V3 d, flo
     t = root;
     return true;
 }
-template <bool UNIFORM = false>
+// STATIC: nothing in the scene moves -- the centre is the record's first float4, the second is not read
+template <bool UNIFORM = false, bool STATIC = false>
 __device__ __forceinline__ bool hit_sphere(const float4 *__restrict__ S, V3 o, V3 d, float time, float tlo,
                                            float thi, bool from_self, float &t) {
+    if (STATIC) return hit_sphere<true>(load4<UNIFORM>(S, 0), make_float4(0.f, 0.f, 0.f, 0.f), o, d, 0.0f, tlo, thi, from_self, t);
     return hit_sphere(load4<UNIFORM>(S, 0), load4<UNIFORM>(S, 1), o, d, time, tlo, thi, from_self, t);
 }
 
@@ -409,7 +414,8 @@ __device__ __forceinline__ bool hit_wide_box(const float4 *__restrict__ B, V3 o,
 
 // EXTRAS: the tree may hold box leaves (false compiles their test out: the kernels behind a tree sit at
 // their register limit, and a scene without such leaves ran 3 % slower with the test compiled in).
-template <bool UNIFORM = false, bool EXTRAS = true>
+// PLAIN: nothing moves and there is no medium (see k_paths).
+template <bool UNIFORM = false, bool EXTRAS = true, bool PLAIN = false>
 __device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, float time, float tlo,
                                           uint32_t origin_ref, const RayCtx &rc, Best &best, V3 inv = V3{0.f, 0.f, 0.f}) {
     uint32_t kind = r >> RT_REF_KIND_SHIFT, idx = r & RT_REF_INDEX_MASK;
@@ -434,9 +440,9 @@ __device__ __forceinline__ void test_prim(SceneRef sc, uint32_t r, V3 o, V3 d, f
         // (A sphere never takes a tie from a quad: its root must lie strictly inside the interval.)
         if (h && t == best.t && (best.ref >> RT_REF_KIND_SHIFT) == RT_KIND_QUAD && best.ref > r) h = false;
     } else if (kind == RT_KIND_SPHERE) {
-        h = hit_sphere<UNIFORM>(sc.spheres + 3 * idx, o, d, time, tlo, best.t, r == origin_ref, t);
+        h = hit_sphere<UNIFORM, PLAIN>(sc.spheres + 3 * idx, o, d, time, tlo, best.t, r == origin_ref, t);
     } else {
-        h = hit_medium(sc, idx, o, d, time, tlo, best.t, rc, t);
+        h = PLAIN ? false : hit_medium(sc, idx, o, d, time, tlo, best.t, rc, t);
     }
     if (h) {
         best.t = t;
@@ -687,7 +693,7 @@ key[a] = ka, key[b] = kb, ref[a] = ra_, ref[b] = rb_;                           
 // says no (asked after every round, wave-uniform; both counts are of the calling lanes).  The
 // per-ray constants are made once per call: a caller that came back for every round paid for them
 // -- three reciprocals and the plane offsets -- once per primitive test.  Returns the rounds run.
-template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK, bool EXTRAS = true, typename More>
+template <bool STAGED, bool QUANT = false, bool SPILL = false, uint32_t STRIDE = BLOCK, bool EXTRAS = true, bool PLAIN = false, typename More>
 __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float time, float tlo, uint32_t origin_ref,
                                                  const RayCtx &rc, const TravMem &mem, uint32_t &cur, uint32_t &sp, Best &best,
                                                  More more, TravStats *ts = nullptr) {
@@ -760,7 +766,7 @@ __device__ __forceinline__ uint32_t trav4_rounds(SceneRef sc, V3 o, V3 d, float 
         if (cur != RT_REF_NONE && (cur >> RT_REF_KIND_SHIFT) != RT_KIND_NODE) {
             // a leaf's word carries the class of its material above the index (rt_accel.h)
             const uint32_t before = best.ref;
-            test_prim<false, EXTRAS>(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best, V3{rcn.ix, rcn.iy, rcn.iz});
+            test_prim<false, EXTRAS, PLAIN>(sc, cur & ~RT4_CLASS_MASK, o, d, time, tlo, origin_ref, rc, best, V3{rcn.ix, rcn.iy, rcn.iz});
             if (best.ref != before) best.cls = (cur & RT4_CLASS_MASK) >> RT4_CLASS_SHIFT;
             cur = sp ? trav_pop<SPILL, STRIDE>(mem, sp) : RT_REF_NONE;
         }
@@ -1188,6 +1194,28 @@ __device__ __forceinline__ float lights_pdf(SceneRef sc, V3 p, V3 dir) {
     return sum;
 }
 
+// light_random in two parts, for a caller that samples a cone and a cosine lobe through ONE local frame:
+// a parallelogram gives the direction itself (returns false); a sphere gives the frame's axis (unit),
+// the azimuth and the local coordinates (s, z) of the cone sample -- the numbers light_random puts
+// through its own basis, bit for bit.
+template <bool UNIFORM>
+__device__ __forceinline__ bool light_random_parts(SceneRef sc, uint32_t i, V3 p, Rng &rng, V3 &dir, V3 &axis, float &phi, float &s, float &z) {
+    const float4 *L = sc.light_recs + 8 * size_t(i);
+    const float4 l0 = load4<UNIFORM>(L, 0), lu = load4<UNIFORM>(L, 4), lv = load4<UNIFORM>(L, 5); // one round trip
+    const float r1 = rng.next();
+    const float r2 = rng.next();
+    if (!(l0.w > 0.0f)) {
+        dir = fma3(mk(lv), r2, fma3(mk(lu), r1, mk(l0))) - p;
+        return false;
+    }
+    const V3 to = mk(l0) - p;
+    axis = unit(to);
+    z = 1.0f + r2 * (fsqrt(1.0f - l0.w * l0.w * rcp(len2(to))) - 1.0f);
+    phi = r1;
+    s = fsqrt(fmaxf(0.f, 1.0f - z * z));
+    return true;
+}
+
 // ------------------------------------------------------------------ camera (camera.rs:409-430)
 // rng: the (pixel, stratum) camera stream, begun by the caller
 __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t stratum, Rng &rng, V3 &o,
@@ -1390,12 +1418,13 @@ struct Surface {
 // through its loop; they are recomputed here for the materials that look at them.
 // DEPOSIT = false: the caller knows the hit is a surface that scatters (k_paths_regroup's scatter
 // steps); only `sf` is wanted.  TABLES: quads, spheres and materials come from `tb`.
-template <bool DEPOSIT = true, bool TABLES = false, bool EXTRAS = true>
+// PLAIN: nothing moves, there is no medium and every material's texture is a colour folded into its record.
+template <bool DEPOSIT = true, bool TABLES = false, bool EXTRAS = true, bool PLAIN = false>
 __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &film, const float4 &ra,
                                            const float4 &rb, const float4 &sa, float4 h, bool quad_uv_missing,
                                            Surface &sf, const FlatTables &tb = FlatTables{}) {
     const V3 o = mk(ra), d = mk(rb), thr = mk(sa);
-    const float time = ra.w;
+    const float time = PLAIN ? 0.0f : ra.w;
     const uint32_t pixel = fbits(sa.w);
     const uint32_t ref = fbits(h.y);
     // one deposit site for the two ways a path ends here (background, emission)
@@ -1435,12 +1464,12 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
                 s0 = S[0], s1 = S[1];
                 u_shift = S[2].z;
             }
-            V3 center = fma3(mk(s1), time, mk(s0));
+            V3 center = PLAIN ? mk(s0) : fma3(mk(s1), time, mk(s0));
             n = (p - center) * rcp(s0.w);
             mat_id = fbits(s1.w);
         } else { // ConstantMedium: arbitrary normal, front face (hittable.rs:877-885)
             n = {1.f, 0.f, 0.f};
-            mat_id = sc.media[idx].mat;
+            mat_id = PLAIN ? 0u : sc.media[idx].mat;
         }
         if (kind != RT_KIND_MEDIUM) { // HitRecord::from_incoming_ray (hittable.rs:59-79)
             front = dot(d, n) < 0.0f;
@@ -1449,15 +1478,15 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
         rt_material m;
         if (TABLES) m = tb.mats[mat_id];
         else m = sc.mats[mat_id];
-        if (kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
+        if (!PLAIN && kind == RT_KIND_SPHERE && m.needs_uv) sphere_uv(front ? n : -n, u_shift, u, v);
         // (a face of a box leaf of the wide tree comes without its (alpha, beta) too: NaN)
-        if (kind == RT_KIND_QUAD && m.needs_uv) {
+        if (!PLAIN && kind == RT_KIND_QUAD && m.needs_uv) {
             if (quad_uv_missing) quad_uv(sc.quads + 6 * idx, p, u, v);
             else if (EXTRAS && u != u) quad_uv_ray(sc.quads + 6 * idx, o, d, h.x, u, v);
         }
         if (DEPOSIT && m.type == RT_MAT_LIGHT) { // material.rs:78-92: emits on the front face, never scatters
             // m.pad != 0: the texture is a SolidColor whose value the upload copied into m.albedo
-            if (front) deposit = m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p);
+            if (front) deposit = (PLAIN || m.pad) ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, u, v, p);
         } else {
             sf.p = p, sf.n = n, sf.u = u, sf.v = v, sf.ref = ref, sf.front = front, sf.m = m;
             surface = true;
@@ -1473,7 +1502,10 @@ __device__ __forceinline__ bool shade_emit(SceneRef sc, CamRef cam, const Film &
 // RT_MAT_DIELECTRIC, or RT_MAT_LAMBERTIAN for the two materials that scatter through a PDF; the
 // other branches are compiled out.  SCATTER_ANY: every material, chosen per lane.
 constexpr uint32_t SCATTER_ANY = 0xFFu;
-template <int MODE, uint32_t ONLY = SCATTER_ANY>
+// ONE_BASIS: the cosine sample and a sphere light's cone sample go through one local frame (one basis,
+// one sine and cosine, one transform for the lanes of both); the same numbers as the separate ones.
+// PLAIN: see shade_emit (no Isotropic material either: it is the phase function of a medium).
+template <int MODE, uint32_t ONLY = SCATTER_ANY, bool ONE_BASIS = false, bool PLAIN = false>
 __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &ra, float4 &rb, float4 &sa,
                                               uint2 &sb, const Surface &sf, Rng &rng, Ctrl *ctrl) {
     const V3 d = mk(rb), p = sf.p, n = sf.n;
@@ -1512,8 +1544,8 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
         att = {1.f, 1.f, 1.f};
     } else {
         // Lambertian (material.rs:45-63) or Isotropic (material.rs:198-212)
-        const bool iso = m.type == RT_MAT_ISOTROPIC;
-        att = m.pad ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, sf.u, sf.v, p);
+        const bool iso = !PLAIN && m.type == RT_MAT_ISOTROPIC;
+        att = (PLAIN || m.pad) ? V3{m.albedo[0], m.albedo[1], m.albedo[2]} : tex_value(sc, m.tex, sf.u, sf.v, p);
         float spdf, pdf;
         if (MODE == RT_MODE_REF_EXACT) {
             // Shipped estimator: the material's own sample only feeds scattering_pdf
@@ -1531,9 +1563,34 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
             pdf = lights_pdf(sc, p, dir);
         } else {
             // 0.5 light list + 0.5 material PDF (pdf.rs:62-90), intended branch order
-            ONB uvw(n, true);
             bool pick_light = false;
             if (sc.lights_kind != RT_LIGHTS_NONE) pick_light = rng.next() < 0.5f;
+            if (ONE_BASIS) {
+                V3 axis = n;
+                float phi = 0.f, sr = 0.f, z = 0.f;
+                bool framed = true;
+                if (pick_light) {
+                    if (sc.lights_kind == RT_LIGHTS_LIST) {
+                        const uint32_t i = uint32_t(rng.next() * float(sc.n_lights));
+                        framed = light_random_parts<false>(sc, min(i, sc.n_lights - 1), p, rng, dir, axis, phi, sr, z);
+                    } else {
+                        framed = light_random_parts<true>(sc, 0u, p, rng, dir, axis, phi, sr, z);
+                    }
+                } else if (iso) {
+                    dir = random_in_unit_sphere(rng);
+                    framed = false;
+                } else {
+                    phi = rng.next();
+                    const float r2 = rng.next();
+                    sr = fsqrt(r2);
+                    z = fsqrt(1.0f - r2);
+                }
+                if (framed) {
+                    const ONB uvw(axis, true);
+                    dir = uvw.transform(V3{__builtin_amdgcn_cosf(phi) * sr, __builtin_amdgcn_sinf(phi) * sr, z});
+                }
+            } else {
+            ONB uvw(n, true);
             if (pick_light) {
                 dir = lights_random(sc, p, rng);
             } else if (iso) {
@@ -1545,7 +1602,8 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
                 dir = uvw.transform(V3{__builtin_amdgcn_cosf(r1) * sr, __builtin_amdgcn_sinf(r1) * sr,
                                        fsqrt(1.0f - r2)});
             }
-            float cosn = dot(dir, uvw.w) * rsq(len2(dir));
+            }
+            float cosn = dot(dir, n) * rsq(len2(dir)); // (n is the basis' w)
             float mpdf = iso ? 0.25f * RT_INV_PI : fmaxf(0.f, cosn * RT_INV_PI);
             spdf = mpdf; // Lambertian::scattering_pdf == CosinePDF::value; Isotropic likewise
             pdf = sc.lights_kind != RT_LIGHTS_NONE ? 0.5f * lights_pdf(sc, p, dir) + 0.5f * mpdf : mpdf;
@@ -1645,7 +1703,10 @@ __device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
 // Registers are held to 128 per lane (4 waves per SIMD): measured faster than 3 waves with no
 // spills or 5, 6, 8 with more, on every workload, flat and BVH.
 // EXTRAS (wide tree): the scene has box leaves or primitives tested after the walk.
-template <int MODE, int ACCEL, bool EXTRAS = true>
+// PLAIN (wide tree): nothing in the scene moves, it has no medium and no Isotropic material, and every
+// texture is a colour folded into its material's record -- the code for all of that is compiled out
+// (the kernel sits at its register limit: +5.5 % on the Book-1 final scene, which is such a scene).
+template <int MODE, int ACCEL, bool EXTRAS = true, bool PLAIN = false>
 __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
                                                   uint32_t has_media, uint32_t grab, uint32_t refill_min) {
     SceneRef sc = *as_uniform(scp);
@@ -1708,9 +1769,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                     // rounds until the lanes that finish bring the shading steps their quorum
                     auto more = [&](uint32_t n_trav, uint32_t n_fin) { return n_trav != 0 && n_work + n_fin < SHADE_QUORUM; };
                     if (sc.lds_nodes4) // uniform
-                        trav4_rounds<true, ACCEL == ACCEL_BVH4Q, false, BLOCK, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
+                        trav4_rounds<true, ACCEL == ACCEL_BVH4Q, false, BLOCK, EXTRAS, PLAIN>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
                     else
-                        trav4_rounds<false, ACCEL == ACCEL_BVH4Q, false, BLOCK, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
+                        trav4_rounds<false, ACCEL == ACCEL_BVH4Q, false, BLOCK, EXTRAS, PLAIN>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more RT_PK_TS);
                 }
                 RT_PK_COUNT(5, n_busy);
                 RT_PK_TICK(5);
@@ -1723,8 +1784,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                     RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
                     test_post(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, best);
                 }
-                scatter = shade_emit<true, false, EXTRAS>(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
-                                                          false, sf);
+                scatter = shade_emit<true, false, EXTRAS, PLAIN>(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
+                                                                 false, sf);
             }
             RT_PK_COUNT(3, uint32_t(__popcll(__ballot(scatter))));
             RT_PK_TICK(2); // post tests and what the hit itself contributes
@@ -1799,7 +1860,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
 #else
         else if (scatter) {
 #endif
-            alive = shade_scatter<MODE>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+            alive = shade_scatter<MODE, SCATTER_ANY, false, PLAIN>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
         } else if (!fresh && !busy) {
             alive = false;
         }
@@ -1863,6 +1924,9 @@ constexpr uint32_t REGROUP_MAX_STRATA = 1u << 24, REGROUP_MAX_DEPTH = 255u; // w
 static_assert(REGROUP_SLOTS <= 256 && REGROUP_SLOTS >= WAVE && REGROUP_SLOTS_TIMELESS <= 256 && REGROUP_SLOTS_TIMELESS >= WAVE, "slot numbers are bytes");
 #ifndef RT_REGROUP_WAVES
 #define RT_REGROUP_WAVES 4
+#endif
+#ifndef RT_ONE_BASIS
+#define RT_ONE_BASIS 1
 #endif
 static_assert(RG_STATS == RG_LISTS + 2, "the lists' steps, then harvest and refill of k_paths_pool");
 #ifdef RT_REGROUP_STATS
@@ -2122,7 +2186,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                     (void)shade_emit<false, TABLES>(sc, cam, film, ra, rb, sa, make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
                     Rng rng;
                     rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
-                    alive = shade_scatter<MODE, ONLY>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+                    alive = shade_scatter<MODE, ONLY, RT_ONE_BASIS>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
                     if (ONLY == RT_MAT_DIELECTRIC && alive && (sf.ref >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE) {
                         // A ray going into a sphere that nothing else reaches into (marked at
                         // upload) meets that sphere next: the closest-hit query is answered here,
@@ -2218,7 +2282,7 @@ static_assert(POOL_SLOTS <= 256 && POOL_SLOTS >= WAVE && POOL_SLOTS % 8 == 0, "s
 // dynamic LDS of a block: the pools, then [POOL_STACK][WAVE] stack words per wave, then the staged nodes
 constexpr size_t POOL_LDS_FIXED = (BLOCK / WAVE) * (sizeof(TravPool) + size_t(POOL_STACK) * WAVE * sizeof(uint32_t));
 
-template <int MODE, bool QUANT, bool EXTRAS = true>
+template <int MODE, bool QUANT, bool EXTRAS = true, bool PLAIN = false>
 __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1,
                                                         Ctrl *ctrl, uint32_t has_media, uint32_t grab, uint32_t *spill,
                                                         uint32_t lds_nodes) {
@@ -2329,9 +2393,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
                 // costs more than the per-ray constants made again for every round (measured: -12 %)
                 auto more = [](uint32_t, uint32_t) { return false; };
                 if (lds_nodes) // uniform
-                    rounds = trav4_rounds<true, QUANT, true, WAVE, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
+                    rounds = trav4_rounds<true, QUANT, true, WAVE, EXTRAS, PLAIN>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
                 else
-                    rounds = trav4_rounds<false, QUANT, true, WAVE, EXTRAS>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
+                    rounds = trav4_rounds<false, QUANT, true, WAVE, EXTRAS, PLAIN>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
             }
             (void)rounds;
             RT_RG_COUNT(RG_RAY, n_trav);
@@ -2389,7 +2453,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
                         const float4 srb = pool.rb[sl];
                         if (fbits(srb.w) != RG_REF_NOTHING) {
                             Surface sf; // ra holds the hit point: t = 0 from there
-                            (void)shade_emit<true, false>(sc, cam, film, pool.ra[sl], srb, pool.sa[sl], make_float4(0.f, srb.w, 0.f, 0.f), true, sf);
+                            (void)shade_emit<true, false, true, PLAIN>(sc, cam, film, pool.ra[sl], srb, pool.sa[sl], make_float4(0.f, srb.w, 0.f, 0.f), true, sf);
                         }
                     }
                     const uint32_t taken = new_paths(m, sl);
@@ -2408,10 +2472,10 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
                             const uint32_t packed = pool.sb[sl];
                             uint2 ssb = make_uint2(packed & 0xFFFFFFu, packed >> 24);
                             Surface sf;
-                            (void)shade_emit<false, false>(sc, cam, film, sra, srb, ssa, make_float4(0.f, srb.w, 0.f, 0.f), true, sf);
+                            (void)shade_emit<false, false, true, PLAIN>(sc, cam, film, sra, srb, ssa, make_float4(0.f, srb.w, 0.f, 0.f), true, sf);
                             Rng rng;
                             rng.begin(k0, k1, fbits(ssa.w), ssb.x, STREAM_SHADE, ssb.y);
-                            alive = shade_scatter<MODE, ONLY>(sc, cam, sra, srb, ssa, ssb, sf, rng, ctrl);
+                            alive = shade_scatter<MODE, ONLY, false, PLAIN>(sc, cam, sra, srb, ssa, ssb, sf, rng, ctrl);
                             if (alive) {
                                 pool.ra[sl] = sra;
                                 pool.rb[sl] = srb;

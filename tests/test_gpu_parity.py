@@ -900,6 +900,8 @@ def test_flat_world_with_every_material_and_a_medium(device, pipeline):
     assert info["kind"] == "flat" and info["flat_boxes"] == 1
     device.film_resize(72, 56)
     st = device.render(cam.build(), mode=ra.RT_MODE_BOOK3, seed=5, **PIPELINES[pipeline])
+    if st.regrouped:  # a sphere moves and there is a medium: slots keep the ray's time, the scan all its loops
+        assert device.last_kernel_variant() == 1  # RT_VARIANT_REGROUPED alone
     gpu = device.film(1.0 / 16)
     film, _, cnt = orc.render(osb, cam, mode=orc.MODE_BOOK3, seed=5)
     r = helpers.compare_same_stream(gpu, film / 16)
@@ -1218,6 +1220,41 @@ def test_regrouping_kernel_equals_the_lane_bound_one(device):
         assert (~np.isclose(fa, fb, rtol=1e-4, atol=1e-5)).mean() < 0.01
         deep = ra.CameraSettings(**{**c.__dict__, "max_depth": 300})
         assert not device.render(deep.build(), mode=mode, seed=7, regroup=True).regrouped
+
+
+def test_kernels_compiled_for_what_a_scene_lacks_equal_the_general_ones(device):
+    """rt_render takes a compilation of the persistent kernel without the code for what the uploaded
+    scene lacks: a Cornell-type flat world (rectangle, upright-box and sphere records, nothing moving)
+    gets pool slots without the ray's time and a scan without the other loops; behind a tree a scene
+    without motion, media and textures gets a kernel without that code.  The arithmetic is the same,
+    so the sample sets are: equal camera-ray counts, segment counts and films up to a forked path or two
+    (separate compilations contract differently), against RT_FLAG_GENERAL_KERNELS."""
+    from raytracing_amd._ffi import RT_VARIANT_BOXED, RT_VARIANT_EXTRAS, RT_VARIANT_PLAIN, RT_VARIANT_REGROUPED, RT_VARIANT_TIMELESS
+    expect = {"c1": RT_VARIANT_REGROUPED | RT_VARIANT_TIMELESS | RT_VARIANT_BOXED,
+              "c3": RT_VARIANT_REGROUPED | RT_VARIANT_TIMELESS | RT_VARIANT_BOXED,
+              "c2": RT_VARIANT_PLAIN,  # Book-1 final scene: static spheres, colours, no medium
+              "c4": RT_VARIANT_EXTRAS,  # Book-2 final scene: motion, media, textures, box leaves
+              "c5": RT_VARIANT_PLAIN}
+    for name, want in expect.items():
+        host, osb, cam, mode, _ = scene(name, device)
+        c = ra.CameraSettings(**{**cam.__dict__, "image_width": 96, "image_height": 80, "samples_per_px": 16})
+        device.film_resize(96, 80)
+        out = {}
+        for general in (True, False):
+            device.film_clear()
+            st = device.render(c.build(), mode=mode, seed=11, general_kernels=general)
+            got = device.last_kernel_variant()
+            assert got == (want & (RT_VARIANT_REGROUPED | RT_VARIANT_EXTRAS) if general else want), (name, general, got)
+            out[general] = (st, device.film(1.0 / c.effective_spp).astype(np.float64))
+        (a, fa), (b, fb) = out[True], out[False]
+        assert a.camera_rays == b.camera_rays and abs(a.segments - b.segments) <= 1e-3 * a.segments, name
+        if name == "c5":
+            # paths of the stress scene chain mirror and glass bounces off spheres down to r = 0.05, which
+            # amplify a last-bit difference (see test_render_same_stream_pixelwise): its bound there
+            assert (~np.isclose(fa, fb, rtol=5e-2, atol=1e-3)).mean() < 0.036, name
+            assert np.median(np.abs(fa - fb) / np.maximum(np.abs(fa), 1e-3)) < 2e-4, name
+        else:
+            assert (~np.isclose(fa, fb, rtol=1e-4, atol=1e-5)).mean() < 0.01, name
 
 
 def test_maximum_sizes(device):
