@@ -486,9 +486,9 @@ int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, con
 }
 
 // The regrouping variant of the persistent kernel (flat worlds): same launch shape.
-template <int MODE, bool TABLES, bool TIMELESS, bool BOXED = false>
+template <int MODE, bool TABLES, bool TIMELESS, bool BOXED = false, uint32_t LIGHTS = LIGHTS_ANY>
 int launch_paths_regroup(rt_handle *h, const rt_render_params *p, const Film &film, unsigned long long total) {
-    auto kernel = k_paths_regroup<MODE, TABLES, TIMELESS, BOXED>;
+    auto kernel = k_paths_regroup<MODE, TABLES, TIMELESS, BOXED, LIGHTS>;
     int per_cu = 0, n_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0));
     RT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
@@ -573,12 +573,14 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
         // a small scene's quads, spheres and materials are copied into LDS tables
         const bool tables = h->n_quads <= TABLE_QUADS && h->n_spheres <= TABLE_SPHERES && h->n_materials <= TABLE_MATERIALS;
         // (in a scene in which nothing moves a slot of the pool does without the ray's time: more slots)
-        // (a Cornell box -- rectangles, upright boxes, spheres, no medium -- takes a scan without the other loops)
+        // (a Cornell box -- rectangles, upright boxes, spheres in plain colours, nothing moving, no medium -- takes a
+        // scan without the other loops and shading without textures)
         const bool timeless = dc.timeless && !general;
-        const bool boxed = !general && tables && !h->has_media && h->sc.n_flat_pairs == 0 && h->sc.n_flat_quads == 0 && h->sc.n_flat_other == 0 &&
+        const bool boxed = timeless && tables && !h->has_media && h->plain_materials && h->sc.n_flat_pairs == 0 && h->sc.n_flat_quads == 0 && h->sc.n_flat_other == 0 &&
                            h->sc.n_flat_boxes == h->sc.n_flat_boxes_aligned + h->sc.n_flat_boxes_upright;
 #define RT_REGROUP(MODE)                                                                                                  \
-    (boxed  ? (timeless ? launch_paths_regroup<MODE, true, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false, true>(h, p, film, total)) \
+    (boxed  ? (h->sc.lights_kind == RT_LIGHTS_LIST ? launch_paths_regroup<MODE, true, true, true, RT_LIGHTS_LIST>(h, p, film, total) \
+                                                   : launch_paths_regroup<MODE, true, true, true>(h, p, film, total)) \
      : tables ? (timeless ? launch_paths_regroup<MODE, true, true>(h, p, film, total) : launch_paths_regroup<MODE, true, false>(h, p, film, total)) \
             : (timeless ? launch_paths_regroup<MODE, false, true>(h, p, film, total) : launch_paths_regroup<MODE, false, false>(h, p, film, total)))
         rc = p->mode == RT_MODE_REF_EXACT ? RT_REGROUP(RT_MODE_REF_EXACT) : RT_REGROUP(RT_MODE_BOOK3);

@@ -59,6 +59,9 @@ struct TravStats { // of the wide traversal, per wave
 struct TravStats {};
 #endif
 
+// LIGHTS template arguments: what the caller knows about DScene::lights_kind
+constexpr uint32_t LIGHTS_ANY = 0xFFu;
+#define RT_LKIND(sc) (LIGHTS == LIGHTS_ANY ? (sc).lights_kind : LIGHTS)
 struct DScene {
     const rt_node *nodes;
     const uint32_t *refs;
@@ -1180,15 +1183,17 @@ __device__ __forceinline__ float light_pdf(SceneRef sc, uint32_t i, V3 p, V3 dir
     return rcp(2.0f * RT_PI * (1.0f - cos_max));
 }
 
+template <uint32_t LIGHTS = LIGHTS_ANY>
 __device__ __forceinline__ V3 lights_random(SceneRef sc, V3 p, Rng &rng) {
-    if (sc.lights_kind == RT_LIGHTS_LIST) {
+    if (RT_LKIND(sc) == RT_LIGHTS_LIST) {
         uint32_t i = uint32_t(rng.next() * float(sc.n_lights));
         return light_random<false>(sc, min(i, sc.n_lights - 1), p, rng);
     }
     return light_random<true>(sc, 0u, p, rng);
 }
+template <uint32_t LIGHTS = LIGHTS_ANY>
 __device__ __forceinline__ float lights_pdf(SceneRef sc, V3 p, V3 dir) {
-    if (sc.lights_kind != RT_LIGHTS_LIST) return light_pdf<true>(sc, 0u, p, dir);
+    if (RT_LKIND(sc) != RT_LIGHTS_LIST) return light_pdf<true>(sc, 0u, p, dir);
     float w = rcp(float(sc.n_lights)), sum = 0.f;
     for (uint32_t i = 0; i < sc.n_lights; ++i) sum += w * light_pdf<true>(sc, i, p, dir);
     return sum;
@@ -1505,7 +1510,8 @@ constexpr uint32_t SCATTER_ANY = 0xFFu;
 // ONE_BASIS: the cosine sample and a sphere light's cone sample go through one local frame (one basis,
 // one sine and cosine, one transform for the lanes of both); the same numbers as the separate ones.
 // PLAIN: see shade_emit (no Isotropic material either: it is the phase function of a medium).
-template <int MODE, uint32_t ONLY = SCATTER_ANY, bool ONE_BASIS = false, bool PLAIN = false>
+// LIGHTS: DScene::lights_kind if the caller knows it (the branches on it are compiled out), else LIGHTS_ANY.
+template <int MODE, uint32_t ONLY = SCATTER_ANY, bool ONE_BASIS = false, bool PLAIN = false, uint32_t LIGHTS = LIGHTS_ANY>
 __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &ra, float4 &rb, float4 &sa,
                                               uint2 &sb, const Surface &sf, Rng &rng, Ctrl *ctrl) {
     const V3 d = mk(rb), p = sf.p, n = sf.n;
@@ -1559,18 +1565,18 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
                 // n . unit(onb.transform(cosine sample)) = sqrt(1-r2)
                 spdf = fmaxf(0.f, fsqrt(1.0f - r2) * RT_INV_PI);
             }
-            dir = lights_random(sc, p, rng);
-            pdf = lights_pdf(sc, p, dir);
+            dir = lights_random<LIGHTS>(sc, p, rng);
+            pdf = lights_pdf<LIGHTS>(sc, p, dir);
         } else {
             // 0.5 light list + 0.5 material PDF (pdf.rs:62-90), intended branch order
             bool pick_light = false;
-            if (sc.lights_kind != RT_LIGHTS_NONE) pick_light = rng.next() < 0.5f;
+            if (RT_LKIND(sc) != RT_LIGHTS_NONE) pick_light = rng.next() < 0.5f;
             if (ONE_BASIS) {
                 V3 axis = n;
                 float phi = 0.f, sr = 0.f, z = 0.f;
                 bool framed = true;
                 if (pick_light) {
-                    if (sc.lights_kind == RT_LIGHTS_LIST) {
+                    if (RT_LKIND(sc) == RT_LIGHTS_LIST) {
                         const uint32_t i = uint32_t(rng.next() * float(sc.n_lights));
                         framed = light_random_parts<false>(sc, min(i, sc.n_lights - 1), p, rng, dir, axis, phi, sr, z);
                     } else {
@@ -1592,7 +1598,7 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
             } else {
             ONB uvw(n, true);
             if (pick_light) {
-                dir = lights_random(sc, p, rng);
+                dir = lights_random<LIGHTS>(sc, p, rng);
             } else if (iso) {
                 dir = random_in_unit_sphere(rng);
             } else {
@@ -1606,7 +1612,7 @@ __device__ __forceinline__ bool shade_scatter(SceneRef sc, CamRef cam, float4 &r
             float cosn = dot(dir, n) * rsq(len2(dir)); // (n is the basis' w)
             float mpdf = iso ? 0.25f * RT_INV_PI : fmaxf(0.f, cosn * RT_INV_PI);
             spdf = mpdf; // Lambertian::scattering_pdf == CosinePDF::value; Isotropic likewise
-            pdf = sc.lights_kind != RT_LIGHTS_NONE ? 0.5f * lights_pdf(sc, p, dir) + 0.5f * mpdf : mpdf;
+            pdf = RT_LKIND(sc) != RT_LIGHTS_NONE ? 0.5f * lights_pdf<LIGHTS>(sc, p, dir) + 0.5f * mpdf : mpdf;
         }
         weight = spdf * rcp(pdf);
         if (!(pdf > 0.0f) || !(fabsf(weight) <= 3.0e38f)) { // would be inf/NaN radiance
@@ -1937,13 +1943,16 @@ static_assert(RG_STATS == RG_LISTS + 2, "the lists' steps, then harvest and refi
 
 // TABLES: the scene is small enough for FlatTables (the launch checks the counts).
 // TIMELESS: nothing in the scene moves, every ray's time is 0 (DCamera::timeless) and a slot does without it.
-// BOXED: see scan_flat (such a world has no medium).
-template <int MODE, bool TABLES, bool TIMELESS, bool BOXED = false>
+// BOXED: see scan_flat; moreover nothing moves (TIMELESS), there is no medium and no Isotropic material, and
+// every texture is a colour folded into its material's record (PLAIN of shade_emit / shade_scatter).
+// LIGHTS: see shade_scatter.
+template <int MODE, bool TABLES, bool TIMELESS, bool BOXED = false, uint32_t LIGHTS = LIGHTS_ANY>
 __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const DScene *scp, const DCamera *camp, Film film, uint32_t k0,
                                                           uint32_t k1, Ctrl *ctrl, uint32_t has_media, uint32_t grab,
                                                           uint32_t n_quads, uint32_t n_spheres, uint32_t n_mats, uint32_t first_take) {
     SceneRef sc = *as_uniform(scp);
     CamRef cam = *as_uniform(camp);
+    static_assert(!BOXED || (TIMELESS && TABLES), "the boxed variant is compiled for still scenes with tables");
     typedef RegroupPool<TIMELESS> Pool;
     constexpr uint32_t SLOTS = Pool::SLOTS;
     __shared__ Pool s_pool[BLOCK / WAVE];
@@ -2108,7 +2117,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                 const float4 rb = pool.rb[slot];
                 if (fbits(rb.w) != RG_REF_NOTHING) {
                     Surface sf; // ra holds the hit point: t = 0 from there
-                    (void)shade_emit<true, TABLES>(sc, cam, film, timed(pool.ra[slot]), rb, pool.sa[slot], make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
+                    (void)shade_emit<true, TABLES, true, BOXED>(sc, cam, film, timed(pool.ra[slot]), rb, pool.sa[slot], make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
                 }
             }
             const uint32_t taken = new_paths(m, slot);
@@ -2183,10 +2192,10 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
                     ra = timed(ra);
                     uint2 sb = make_uint2(packed & 0xFFFFFFu, packed >> 24);
                     Surface sf; // ra holds the hit point: t = 0 from there
-                    (void)shade_emit<false, TABLES>(sc, cam, film, ra, rb, sa, make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
+                    (void)shade_emit<false, TABLES, true, BOXED>(sc, cam, film, ra, rb, sa, make_float4(0.f, rb.w, 0.f, 0.f), true, sf, tb);
                     Rng rng;
                     rng.begin(k0, k1, fbits(sa.w), sb.x, STREAM_SHADE, sb.y);
-                    alive = shade_scatter<MODE, ONLY, RT_ONE_BASIS>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+                    alive = shade_scatter<MODE, ONLY, RT_ONE_BASIS, BOXED, LIGHTS>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
                     if (ONLY == RT_MAT_DIELECTRIC && alive && (sf.ref >> RT_REF_KIND_SHIFT) == RT_KIND_SPHERE) {
                         // A ray going into a sphere that nothing else reaches into (marked at
                         // upload) meets that sphere next: the closest-hit query is answered here,
@@ -2269,6 +2278,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
 #ifndef RT_POOL_STARVE
 #define RT_POOL_STARVE 40
 #endif
+
 constexpr int POOL_SLOTS = RT_POOL_SLOTS;       // paths per wave
 constexpr uint32_t POOL_STACK = RT_POOL_STACK;  // LDS stack entries per lane
 constexpr uint32_t POOL_HARVEST = RT_POOL_HARVEST; // ended traversals that make the wave stop for a harvest
@@ -2388,10 +2398,18 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths_pool(const DScene *scp, cons
             // 1. a traversal round for the lanes that hold a ray
             uint32_t rounds = 0;
             if (traversing) {
-                // one round per call: running them here until the pool has something else to do keeps 16 more
-                // scalar registers live through the rounds, and what the kernel then spills to vector lanes
-                // costs more than the per-ray constants made again for every round (measured: -12 %)
-                auto more = [](uint32_t, uint32_t) { return false; };
+                // One round per call in the kernel compiled for any scene: running them here until the pool has
+                // something else to do keeps 16 more scalar registers live through the rounds, and what that
+                // kernel then spills to vector lanes costs more than the per-ray constants made again for every
+                // round (measured: -12 %).  The PLAIN kernel has the registers (+1 % on the 1 M-primitive scene):
+                // rounds until the conditions of the loop's head, with the lanes that finish inside the call
+                // counted in, say that the pool has something else for the wave to do.
+                auto more = [&](uint32_t nt, uint32_t nf) {
+                    if (!PLAIN) return false;
+                    const bool refill = n_ray != 0 && uint32_t(WAVE) - nt >= POOL_HARVEST;
+                    const bool shade = fullest >= uint32_t(WAVE) || ((fullest != 0 || (!exhausted && n_free != 0)) && nt < POOL_STARVE && n_ray == 0);
+                    return nt != 0 && n_done + nf < POOL_HARVEST && !refill && !shade;
+                };
                 if (lds_nodes) // uniform
                     rounds = trav4_rounds<true, QUANT, true, WAVE, EXTRAS, PLAIN>(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, mem, cur, sp, best, more);
                 else
