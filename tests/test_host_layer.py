@@ -62,6 +62,20 @@ def test_abi_handshake():
     assert pad.info.flat_rects == 1
 
 
+def test_flag_and_variant_constants_mirror_the_header():
+    """The ctypes mirror's RT_FLAG_* / RT_VARIANT_* equal the header's; the diagnostic takes NULL."""
+    header = (ROOT / "include" / "rt_amd.h").read_text()
+    names = re.findall(r"#define (RT_FLAG_[A-Z_]+|RT_VARIANT_[A-Z_]+) (\d+)u", header)
+    assert {n for n, _ in names} >= {"RT_FLAG_TIME_KERNELS", "RT_FLAG_WAVEFRONT", "RT_FLAG_REGROUP", "RT_FLAG_NO_REGROUP",
+                                     "RT_FLAG_GENERAL_KERNELS", "RT_VARIANT_REGROUPED", "RT_VARIANT_TIMELESS", "RT_VARIANT_BOXED",
+                                     "RT_VARIANT_PLAIN", "RT_VARIANT_EXTRAS"}
+    for name, value in names:
+        assert getattr(_ffi, name) == int(value), name
+    flags = [int(v) for n, v in names if n.startswith("RT_FLAG_")]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)  # distinct single bits
+    assert lib.rt_last_kernel_variant(None) == 0
+
+
 def test_no_gpu_means_loud_failure():
     if ra.device_count() > 0:
         pytest.skip("a GPU is visible here")
