@@ -207,6 +207,65 @@ def test_flatten_cornell_is_one_flat_list_in_reference_order():
     assert np.allclose(list(green.color), [0x1F / 255, 0x73 / 255, 0x26 / 255])
 
 
+def test_book_scene_constants_are_the_books():
+    """The oracle's scenes are built by the same scene functions as the product's, so a wrong constant
+    there would be invisible to parity: the numbers of the three book scenes, written out here from
+    "In One Weekend" / "The Next Week" / "The Rest of Your Life" and read back from the flattened
+    descriptors (main.rs's own scene is pinned in test_flatten_cornell_is_one_flat_list_in_reference_order)."""
+    def arrays(fn, **kw):
+        sb = ra.SceneBuilder()
+        cam = fn(sb, **kw)
+        d = sb.flatten().contents
+        sph = {tuple(round(x, 3) for x in d.spheres[i].c0) + (round(d.spheres[i].radius, 3),): d.spheres[i] for i in range(d.n_spheres)}
+        mats = [d.materials[i] for i in range(d.n_materials)]
+        keep.append(sb)  # the descriptor's arrays belong to the builder
+        return d, cam, sph, mats
+    keep = []
+    header = (ROOT / "include" / "rt_amd.h").read_text()
+    K = {n: int(v) for n, v in re.findall(r"#define (RT_(?:MAT|TEX|LIGHTS)_[A-Z]+) (\d+)u", header)}
+    LAMB, LIGHT, METAL, GLASS = K["RT_MAT_LAMBERTIAN"], K["RT_MAT_LIGHT"], K["RT_MAT_METAL"], K["RT_MAT_DIELECTRIC"]
+
+    # Book 3, Cornell box with a glass sphere: walls + lamp + tall box + ball; lamp and ball in the light list
+    d, cam, sph, mats = arrays(ra.scenes.cornell_book3)
+    assert (d.n_quads, d.n_spheres, d.n_lights, d.lights_kind) == (12, 1, 2, K["RT_LIGHTS_LIST"])
+    ball = sph[(190.0, 90.0, 190.0, 90.0)]
+    assert mats[ball.mat].type == GLASS and mats[ball.mat].param == 1.5
+    lamp = [d.quads[i] for i in range(d.n_quads) if mats[d.quads[i].mat].type == LIGHT]
+    assert len(lamp) == 1 and list(lamp[0].q) == [343.0, 554.0, 332.0] and lamp[0].area == 130.0 * 105.0
+    assert (cam.image_width, cam.image_height, cam.effective_spp, cam.max_depth, cam.vfov) == (1200, 1200, 961, 50, 40.0)
+    assert cam.camera_center == (278.0, 278.0, -800.0) and cam.camera_target == (278.0, 278.0, 0.0)
+
+    # Book 1, final scene: ground, 22 x 22 small spheres (minus those near the metal one), three big ones
+    d, cam, sph, mats = arrays(ra.scenes.book1_final)
+    assert 440 <= d.n_spheres <= 488 and d.n_quads == 0 and d.lights_kind == K["RT_LIGHTS_NONE"]
+    ground, glass, matte, metal = sph[(0.0, -1000.0, 0.0, 1000.0)], sph[(0.0, 1.0, 0.0, 1.0)], sph[(-4.0, 1.0, 0.0, 1.0)], sph[(4.0, 1.0, 0.0, 1.0)]
+    assert mats[ground.mat].type == LAMB and mats[glass.mat].type == GLASS and mats[glass.mat].param == 1.5
+    assert mats[matte.mat].type == LAMB and mats[metal.mat].type == METAL and mats[metal.mat].param == 0.0
+    assert np.allclose(list(mats[metal.mat].albedo), [0.7, 0.6, 0.5]) and sum(1 for k in sph if k[3] == 0.2) == d.n_spheres - 4
+    assert (cam.image_width, cam.image_height, cam.effective_spp, cam.vfov, cam.defocus_angle, cam.focal_length) == (1200, 675, 484, 20.0, 0.6, 10.0)
+    assert cam.camera_center == (13.0, 2.0, 3.0) and cam.camera_target == (0.0, 0.0, 0.0)
+
+    # Book 2, final scene (a miniature of the box field and the cloud: the named objects are what is checked)
+    d, cam, sph, mats = arrays(ra.scenes.book2_final, boxes_per_side=2, cloud=3, earth=ra.scenes.synthetic_earth(8, 4))
+    moving = sph[(400.0, 400.0, 200.0, 50.0)]
+    assert list(moving.cv) == [30.0, 0.0, 0.0] and mats[moving.mat].type == LAMB
+    assert mats[sph[(260.0, 150.0, 45.0, 50.0)].mat].type == GLASS
+    fuzzy = mats[sph[(0.0, 150.0, 145.0, 50.0)].mat]
+    assert fuzzy.type == METAL and fuzzy.param == 1.0 and np.allclose(list(fuzzy.albedo), [0.8, 0.8, 0.9])
+    media = sorted((d.media[i].neg_inv_density for i in range(d.n_media)))
+    assert d.n_media == 2 and np.allclose(media, [-1.0 / 0.0001, -1.0 / 0.2])
+    assert (360.0, 150.0, 145.0, 70.0) in sph and (0.0, 0.0, 0.0, 5000.0) in sph
+    texs = [d.textures[i] for i in range(d.n_textures)]
+    earth, marble = sph[(400.0, 200.0, 400.0, 100.0)], sph[(220.0, 280.0, 300.0, 80.0)]
+    assert texs[mats[earth.mat].tex].type == K["RT_TEX_IMAGE"] and texs[mats[marble.mat].tex].type == K["RT_TEX_NOISE"]
+    assert abs(texs[mats[marble.mat].tex].scale - 0.2) < 1e-7
+    lamp = [d.quads[i] for i in range(d.n_quads) if mats[d.quads[i].mat].type == LIGHT]
+    assert len(lamp) == 1 and list(lamp[0].q) == [123.0, 554.0, 147.0] and lamp[0].area == 300.0 * 265.0
+    assert list(texs[mats[lamp[0].mat].tex].color) == [7.0, 7.0, 7.0] and d.n_quads == 1 + 6 * 4
+    assert (cam.image_width, cam.image_height, cam.effective_spp, cam.max_depth, cam.vfov) == (800, 800, 10000, 40, 40.0)
+    assert cam.camera_center == (478.0, 278.0, -600.0) and cam.camera_target == (278.0, 278.0, 0.0)
+
+
 def test_flatten_bakes_rotate_translate_like_the_reference_maps_points():
     sb = ra.SceneBuilder()
     ra.scenes.cornell_main(sb)
