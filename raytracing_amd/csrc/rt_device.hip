@@ -1375,6 +1375,7 @@ int rt_render(rt_handle *h, const rt_camera *cam, const rt_render_params *params
     const uint32_t k0 = uint32_t(p->seed), k1 = uint32_t(p->seed >> 32);
     const Film film{h->film, dc.npix};
     if (!(p->flags & RT_FLAG_WAVEFRONT)) return render_persistent(h, dc, p, film, total);
+    h->last_variant = 0; // the ray-queue pipeline has one compilation
 
     // pool geometry: chunks of 512 rays, one wave each
     const uint32_t cap = 512;

@@ -1257,6 +1257,8 @@ def test_kernels_compiled_for_what_a_scene_lacks_equal_the_general_ones(device):
             assert np.median(np.abs(fa - fb) / np.maximum(np.abs(fa), 1e-3)) < 2e-4, name
         else:
             assert (~np.isclose(fa, fb, rtol=1e-4, atol=1e-5)).mean() < 0.01, name
+    device.render(c.build(), mode=mode, seed=11, wavefront=True)
+    assert device.last_kernel_variant() == 0  # the ray-queue pipeline has one compilation
 
 
 def test_maximum_sizes(device):
