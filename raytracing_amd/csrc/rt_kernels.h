@@ -2276,7 +2276,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
 #define RT_POOL_HARVEST 16
 #endif
 #ifndef RT_POOL_STARVE
-#define RT_POOL_STARVE 40
+#define RT_POOL_STARVE 56
 #endif
 
 constexpr int POOL_SLOTS = RT_POOL_SLOTS;       // paths per wave
