@@ -203,6 +203,7 @@ typedef struct {
 #define RT_VARIANT_BOXED 4u     /* flat world of rectangle, upright-box and sphere records only */
 #define RT_VARIANT_PLAIN 8u     /* behind a tree: no motion, no medium, no texture but colours */
 #define RT_VARIANT_EXTRAS 16u   /* behind a tree: box leaves or primitives tested after the walk */
+#define RT_VARIANT_SIMPLE 32u   /* lane-bound kernel with RT_VARIANT_EXTRAS: pinhole camera, square filter, one light */
 typedef struct {
     uint32_t struct_size;                /* = sizeof(rt_render_params) of the caller's header */
     uint32_t mode;

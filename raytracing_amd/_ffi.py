@@ -111,7 +111,7 @@ RT_FLAG_WAVEFRONT = 2
 RT_FLAG_REGROUP = 4
 RT_FLAG_NO_REGROUP = 8
 RT_FLAG_GENERAL_KERNELS = 16
-RT_VARIANT_REGROUPED, RT_VARIANT_TIMELESS, RT_VARIANT_BOXED, RT_VARIANT_PLAIN, RT_VARIANT_EXTRAS = 1, 2, 4, 8, 16
+RT_VARIANT_REGROUPED, RT_VARIANT_TIMELESS, RT_VARIANT_BOXED, RT_VARIANT_PLAIN, RT_VARIANT_EXTRAS, RT_VARIANT_SIMPLE = 1, 2, 4, 8, 16, 32
 RT_KIND_NODE, RT_KIND_QUAD, RT_KIND_SPHERE, RT_KIND_MEDIUM = 0, 1, 2, 3
 RT_COMM_ID_BYTES = 128
 RT_NODE_LEAF = 0xFFFFFFFF

@@ -456,10 +456,10 @@ void drain_timers(rt_handle *h, size_t upto) {
 void drain_timers(rt_handle *h) { drain_timers(h, h->ev_used); }
 
 // One launch of the persistent path kernel: as many blocks as the device keeps resident.
-template <int MODE, int ACCEL, bool EXTRAS = true, bool PLAIN = false>
+template <int MODE, int ACCEL, bool EXTRAS = true, bool PLAIN = false, bool SIMPLE = false>
 int launch_paths(rt_handle *h, const DCamera &dc, const rt_render_params *p, const Film &film,
                  unsigned long long total) {
-    auto kernel = k_paths<MODE, ACCEL, EXTRAS, PLAIN>;
+    auto kernel = k_paths<MODE, ACCEL, EXTRAS, PLAIN, SIMPLE>;
     int per_cu = 0, n_cu = 0;
     const size_t dyn_lds = accel_is_wide(ACCEL) ? h->dyn_lds4() : 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));
@@ -569,6 +569,8 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     const bool general = (p->flags & RT_FLAG_GENERAL_KERNELS) != 0;
     uint32_t variant_flat = 0;
     const bool plain = !general && !extras && dc.timeless && !h->has_media && h->plain_materials;
+    // ... and a scene with them once more for a pinhole camera and a single light
+    const bool simple = !general && extras && !dc.defocus && !dc.aa_disc && h->sc.lights_kind == RT_LIGHTS_SINGLE;
     if (h->accel == ACCEL_FLAT && regroup_wanted && regroup_fits) {
         // a small scene's quads, spheres and materials are copied into LDS tables
         const bool tables = h->n_quads <= TABLE_QUADS && h->n_spheres <= TABLE_SPHERES && h->n_materials <= TABLE_MATERIALS;
@@ -602,10 +604,10 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     } else {
 #define RT_PATHS(MODE)                                                                                    \
     (h->accel == ACCEL_FLAT   ? launch_paths<MODE, ACCEL_FLAT>(h, dc, p, film, total)                        \
-     : h->accel == ACCEL_BVH4 ? (extras  ? launch_paths<MODE, ACCEL_BVH4, true>(h, dc, p, film, total)                \
+     : h->accel == ACCEL_BVH4 ? (extras  ? (simple ? launch_paths<MODE, ACCEL_BVH4, true, false, true>(h, dc, p, film, total) : launch_paths<MODE, ACCEL_BVH4, true>(h, dc, p, film, total)) \
                                  : plain ? launch_paths<MODE, ACCEL_BVH4, false, true>(h, dc, p, film, total)         \
                                          : launch_paths<MODE, ACCEL_BVH4, false>(h, dc, p, film, total))              \
-     : h->accel == ACCEL_BVH4Q ? (extras  ? launch_paths<MODE, ACCEL_BVH4Q, true>(h, dc, p, film, total)              \
+     : h->accel == ACCEL_BVH4Q ? (extras  ? (simple ? launch_paths<MODE, ACCEL_BVH4Q, true, false, true>(h, dc, p, film, total) : launch_paths<MODE, ACCEL_BVH4Q, true>(h, dc, p, film, total)) \
                                   : plain ? launch_paths<MODE, ACCEL_BVH4Q, false, true>(h, dc, p, film, total)       \
                                           : launch_paths<MODE, ACCEL_BVH4Q, false>(h, dc, p, film, total))            \
                               : launch_paths<MODE, ACCEL_BVH2>(h, dc, p, film, total))
@@ -614,7 +616,7 @@ int render_persistent(rt_handle *h, const DCamera &dc, const rt_render_params *p
     }
     if (rc) return rc;
     h->last_variant = (h->stats.regrouped ? RT_VARIANT_REGROUPED : 0u) | (h->accel != ACCEL_FLAT && extras ? RT_VARIANT_EXTRAS : 0u) |
-                      (h->accel != ACCEL_FLAT && plain ? RT_VARIANT_PLAIN : 0u) | variant_flat;
+                      (h->accel != ACCEL_FLAT && plain ? RT_VARIANT_PLAIN : 0u) | (accel_is_wide(h->accel) && !h->stats.regrouped && simple ? RT_VARIANT_SIMPLE : 0u) | variant_flat;
     RT_HIP(hipEventRecord(h->ev_end, h->stream));
     RT_HIP(hipMemcpyAsync(&h->h_ctrl[0], h->d_ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, h->stream));
     RT_HIP(hipStreamSynchronize(h->stream));

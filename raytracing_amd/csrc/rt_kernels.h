@@ -1223,6 +1223,9 @@ __device__ __forceinline__ bool light_random_parts(SceneRef sc, uint32_t i, V3 p
 
 // ------------------------------------------------------------------ camera (camera.rs:409-430)
 // rng: the (pixel, stratum) camera stream, begun by the caller
+// PINHOLE: the caller knows that the camera has neither a defocus disk nor the disc filter (both are
+// rejection loops with a Philox block inside)
+template <bool PINHOLE = false>
 __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t stratum, Rng &rng, V3 &o,
                                            V3 &d, float &time) {
     // row and column by a float reciprocal with one correction step: exact below 2^24, where
@@ -1244,7 +1247,7 @@ __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t 
         si = stratum % cam.sqrt_spp, sj = stratum / cam.sqrt_spp;
     }
     float ox, oy;
-    if (cam.aa_disc) { // AntialiasingType::Disc: r = 0.5 px about the pixel centre, not stratified
+    if (!PINHOLE && cam.aa_disc) { // AntialiasingType::Disc: r = 0.5 px about the pixel centre, not stratified
         for (;;) {
             ox = rng.pm1();
             oy = rng.pm1();
@@ -1263,7 +1266,7 @@ __device__ __forceinline__ void camera_ray(CamRef cam, uint32_t pixel, uint32_t 
     rel = fma3(ldv(cam.dv), oy, rel);
     o = ldv(cam.center);
     d = rel;
-    if (cam.defocus) { // camera.rs:484-488, two_d.rs:183-190
+    if (!PINHOLE && cam.defocus) { // camera.rs:484-488, two_d.rs:183-190
         float px, py;
         for (;;) {
             px = rng.pm1();
@@ -1709,10 +1712,12 @@ __device__ __forceinline__ unsigned long long wave_first(unsigned long long x) {
 // Registers are held to 128 per lane (4 waves per SIMD): measured faster than 3 waves with no
 // spills or 5, 6, 8 with more, on every workload, flat and BVH.
 // EXTRAS (wide tree): the scene has box leaves or primitives tested after the walk.
+// SIMPLE (wide tree, with EXTRAS): the camera is a pinhole with the square filter and `lights` is one
+// primitive -- what is left to compile out for the Book-2 final scene, which has everything else (+2 %).
 // PLAIN (wide tree): nothing in the scene moves, it has no medium and no Isotropic material, and every
 // texture is a colour folded into its material's record -- the code for all of that is compiled out
 // (the kernel sits at its register limit: +5.5 % on the Book-1 final scene, which is such a scene).
-template <int MODE, int ACCEL, bool EXTRAS = true, bool PLAIN = false>
+template <int MODE, int ACCEL, bool EXTRAS = true, bool PLAIN = false, bool SIMPLE = false>
 __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCamera *camp, Film film, uint32_t k0, uint32_t k1, Ctrl *ctrl,
                                                   uint32_t has_media, uint32_t grab, uint32_t refill_min) {
     SceneRef sc = *as_uniform(scp);
@@ -1854,7 +1859,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
         if (fresh) {
             V3 o, d;
             float time;
-            camera_ray(cam, fbits(sa.w), sb.x, rng, o, d, time);
+            camera_ray<SIMPLE>(cam, fbits(sa.w), sb.x, rng, o, d, time);
             ra = make_float4(o.x, o.y, o.z, time);
             rb = make_float4(d.x, d.y, d.z, bitsf(RT_REF_NONE));
             sa = make_float4(1.f, 1.f, 1.f, sa.w);
@@ -1866,7 +1871,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
 #else
         else if (scatter) {
 #endif
-            alive = shade_scatter<MODE, SCATTER_ANY, false, PLAIN>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
+            alive = shade_scatter<MODE, SCATTER_ANY, false, PLAIN, SIMPLE ? uint32_t(RT_LIGHTS_SINGLE) : LIGHTS_ANY>(sc, cam, ra, rb, sa, sb, sf, rng, ctrl);
         } else if (!fresh && !busy) {
             alive = false;
         }

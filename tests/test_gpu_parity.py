@@ -1228,14 +1228,15 @@ def test_kernels_compiled_for_what_a_scene_lacks_equal_the_general_ones(device):
     """rt_render takes a compilation of the persistent kernel without the code for what the uploaded
     scene lacks: a Cornell-type flat world (rectangle, upright-box and sphere records, nothing moving)
     gets pool slots without the ray's time and a scan without the other loops; behind a tree a scene
-    without motion, media and textures gets a kernel without that code.  The arithmetic is the same,
+    without motion, media and textures gets a kernel without that code, one with all of them a kernel
+    for a pinhole camera and a single light where that is what it has.  The arithmetic is the same,
     so the sample sets are: equal camera-ray counts, segment counts and films up to a forked path or two
     (separate compilations contract differently), against RT_FLAG_GENERAL_KERNELS."""
-    from raytracing_amd._ffi import RT_VARIANT_BOXED, RT_VARIANT_EXTRAS, RT_VARIANT_PLAIN, RT_VARIANT_REGROUPED, RT_VARIANT_TIMELESS
+    from raytracing_amd._ffi import RT_VARIANT_BOXED, RT_VARIANT_EXTRAS, RT_VARIANT_PLAIN, RT_VARIANT_REGROUPED, RT_VARIANT_SIMPLE, RT_VARIANT_TIMELESS
     expect = {"c1": RT_VARIANT_REGROUPED | RT_VARIANT_TIMELESS | RT_VARIANT_BOXED,
               "c3": RT_VARIANT_REGROUPED | RT_VARIANT_TIMELESS | RT_VARIANT_BOXED,
               "c2": RT_VARIANT_PLAIN,  # Book-1 final scene: static spheres, colours, no medium
-              "c4": RT_VARIANT_EXTRAS,  # Book-2 final scene: motion, media, textures, box leaves
+              "c4": RT_VARIANT_EXTRAS | RT_VARIANT_SIMPLE,  # Book-2 final scene: motion, media, textures, box leaves; pinhole, one light
               "c5": RT_VARIANT_PLAIN}
     for name, want in expect.items():
         host, osb, cam, mode, _ = scene(name, device)
