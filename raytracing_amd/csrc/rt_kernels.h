@@ -1795,8 +1795,11 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
                     RayCtx rc{k0, k1, fbits(sa.w), sb.x, sb.y};
                     test_post(sc, mk(ra), mk(rb), ra.w, 0.001f, fbits(rb.w), rc, best);
                 }
-                scatter = shade_emit<true, false, EXTRAS, PLAIN>(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), best.u, best.v),
-                                                                 false, sf);
+                // (a quad's (alpha, beta) are not carried through the walk: shade_emit makes them from the hit
+                // point for the materials that look at them, as it does behind the flat scan -- two registers
+                // per lane in a kernel at its limit)
+                scatter = shade_emit<true, false, EXTRAS, PLAIN>(sc, cam, film, ra, rb, sa, make_float4(best.t, bitsf(best.ref), 0.f, 0.f),
+                                                                 true, sf);
             }
             RT_PK_COUNT(3, uint32_t(__popcll(__ballot(scatter))));
             RT_PK_TICK(2); // post tests and what the hit itself contributes
