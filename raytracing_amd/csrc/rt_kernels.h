@@ -1909,8 +1909,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_paths(const DScene *scp, const DCa
 // wave of lane-bound paths.  The pool belongs to one wave: lists are pushed with ballot + mbcnt
 // prefixes, there are no barriers and no atomics.  Every random number is keyed by
 // (pixel, stratum, bounce), so the image equals k_paths'.
-// Exit: a wave leaves when the sample counter has run out and every list but the free one is
-// empty; each step moves its slots on and a path ends within max_depth bounces.
+// Exit: a wave leaves when every list is empty -- once the sample counter has run out, a slot whose
+// path has ended gets no new sample and leaves the lists; each step moves its slots on and a path
+// ends within max_depth bounces.
 #ifndef RT_REGROUP_SLOTS
 #define RT_REGROUP_SLOTS 172
 #endif
