@@ -524,7 +524,14 @@ int launch_paths_pool(rt_handle *h, const rt_render_params *p, const Film &film,
     auto kernel = k_paths_pool<MODE, QUANT, EXTRAS, PLAIN>;
     // what is left of a quarter of the CU's LDS behind pools and stacks holds the top of the tree
     const size_t node_bytes = QUANT ? sizeof(Node4Q) : sizeof(Node4), budget = 40 * 1024;
-    const uint32_t lds_nodes = POOL_LDS_FIXED < budget ? uint32_t(std::min<size_t>(h->accel_stats.nodes, (budget - POOL_LDS_FIXED) / node_bytes)) : 0u;
+    // A large tree is read from memory with plain loads: the few dozen nodes that fit beside the pools make
+    // every node load a generic one (LDS or memory, decided per lane), which costs more than the top of a tree
+    // of hundreds of thousands of nodes saves (1 M-primitive scene: +2.9 % without; small trees -3 to -5 % without).
+#ifndef RT_POOL_STAGE_MAX_NODES
+#define RT_POOL_STAGE_MAX_NODES 4096u
+#endif
+    const uint32_t lds_nodes = POOL_LDS_FIXED < budget && h->accel_stats.nodes <= RT_POOL_STAGE_MAX_NODES
+                                   ? uint32_t(std::min<size_t>(h->accel_stats.nodes, (budget - POOL_LDS_FIXED) / node_bytes)) : 0u;
     const size_t dyn_lds = POOL_LDS_FIXED + lds_nodes * node_bytes;
     int per_cu = 0, n_cu = 0;
     RT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, dyn_lds));

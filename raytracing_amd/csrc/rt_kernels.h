@@ -2276,7 +2276,7 @@ __global__ void __launch_bounds__(BLOCK, RT_REGROUP_WAVES) k_paths_regroup(const
 // Exit: a wave leaves when the sample counter has run out, no lane holds a ray and every list but
 // the free one is empty; every traversal ends (the tree is finite) and every path within max_depth.
 #ifndef RT_POOL_SLOTS
-#define RT_POOL_SLOTS 112
+#define RT_POOL_SLOTS 120
 #endif
 #ifndef RT_POOL_STACK
 #define RT_POOL_STACK 12
